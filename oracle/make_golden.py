@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (imported from /root/reference,
+never copied) on this container's CPU.  Runs only where /root/reference exists; the
+fixtures it writes are committed so that the GPU box (no /root/reference) can check
+against them.
+
+    python oracle/make_golden.py            # writes bnstats_*.npz and golden_*.npz
+
+Step 1 (calibration): load siammask_amd.synth.raw_state_dict() into the
+reference ``Custom`` and set every BatchNorm2d's running statistics to the batch statistics
+of one template + one search pass (BN in train mode with momentum 1.0).
+Step 2 (golden vectors): load the calibrated checkpoint through the reference's own
+``utils/load_helper.load_pretrain`` (the path tools/test.py:566 uses), run the reference in
+float64 and store inputs (uint8), outputs and sub-sampled intermediates.
+"""
+import json
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("SIAMMASK_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+from siammask_amd import synth  # noqa: E402
+from oracle.np_oracle import decode_best  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+EXP = {"sharp": "siammask_sharp", "base": "siammask_base", "rpn": "siamrpn_resnet"}
+ANCHORS = {"stride": 8, "ratios": [0.33, 0.5, 1, 2, 3], "scales": [8], "round_dight": 0}
+
+
+def import_reference_custom(variant):
+    """Import experiments/<exp>/custom.py::Custom from the reference tree."""
+    for m in [k for k in sys.modules if k in ("custom", "resnet")]:
+        del sys.modules[m]
+    exp_dir = os.path.join(REF, "experiments", EXP[variant])
+    sys.path[:] = [p for p in sys.path if "/experiments/" not in p]
+    sys.path.insert(0, exp_dir)
+    if REF not in sys.path:
+        sys.path.insert(1, REF)
+    import custom  # noqa
+    return custom.Custom
+
+
+def build_reference(variant, sd_np, via_load_pretrain=True):
+    Custom = import_reference_custom(variant)
+    model = Custom(anchors=ANCHORS)
+    sd_t = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
+    if via_load_pretrain:
+        from utils.load_helper import load_pretrain
+        with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+            path = f.name
+        torch.save({"state_dict": {"module." + k: v for k, v in sd_t.items()}}, path)
+        load_pretrain(model, path)         # strips 'module.', load_state_dict(strict=False)
+        os.unlink(path)
+    else:
+        missing = model.load_state_dict(sd_t, strict=True)
+    return model.eval()
+
+
+def calibrate(fixture):
+    seed, damp = synth.FIXTURES[fixture]
+    sd = synth.raw_state_dict("sharp", seed, damp)
+    model = build_reference("sharp", sd, via_load_pretrain=False)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.train()
+        m.momentum = 1.0
+    z = np.concatenate([synth.image_batch(2, 127, stream0=100), synth.smooth_image_batch(2, 127, stream0=100)])
+    x = np.concatenate([synth.image_batch(2, 255, stream0=100), synth.smooth_image_batch(2, 255, stream0=100)])
+    with torch.no_grad():
+        model.template(torch.from_numpy(z))
+        model.track_mask(torch.from_numpy(x))
+    for m in bns:
+        m.eval()
+        m.momentum = 0.1
+    stats = {k: v.numpy().astype(np.float32) for k, v in model.state_dict().items()
+             if k.endswith("running_mean") or k.endswith("running_var")}
+    np.savez_compressed(synth.bnstats_path(fixture), **stats)
+    print("calibrated %s: %d stat tensors" % (fixture, len(stats)))
+
+
+def sample(t, n=4096):
+    """Strided sub-sample of a tensor + summary stats (keeps fixtures small)."""
+    a = t.detach().numpy().astype(np.float64).ravel()
+    stride = max(1, a.size // n)
+    if stride > 1 and stride % 2 == 0:
+        stride += 1
+    return {"stride": np.int64(stride), "vals": a[::stride].astype(np.float32),
+            "sum": np.float64(a.sum()), "maxabs": np.float64(np.abs(a).max()),
+            "shape": np.array(t.shape, dtype=np.int64)}
+
+
+def put(store, key, d):
+    for k, v in d.items():
+        store["%s__%s" % (key, k)] = v
+
+
+def run_case(name, variant, fixture, z_u8, x_u8, shared_pos=None):
+    sd = synth.state_dict(variant, fixture)
+    model = build_reference(variant, sd).double()
+    z = torch.from_numpy(z_u8.astype(np.float64))
+    x = torch.from_numpy(x_u8.astype(np.float64))
+    B = x.shape[0]
+    store = {"z_u8": z_u8, "x_u8": x_u8, "variant": variant, "fixture": fixture}
+    with torch.no_grad():
+        model.template(z)
+        put(store, "zf", sample(model.zf))
+        store["zf_full"] = model.zf.numpy().astype(np.float32)
+        if variant == "rpn":
+            cls, loc = model.track(x)
+            mask = None
+        else:
+            cls, loc, mask = model.track_mask(x)
+        # intermediates (run the sub-modules again; eval mode => pure functions)
+        feats = model.features.features(x)
+        names = ("p0", "p1", "p2", "p3") if variant == "sharp" else ("p2", "p3", "p4")
+        for n_, f_ in zip(names, feats):
+            if f_.dim() == 4:
+                put(store, n_, sample(f_))
+        p3 = feats[3] if variant == "sharp" else feats[1]
+        search = model.features.downsample(p3)
+        put(store, "search", sample(search))
+        branches = [("cls", model.rpn_model.cls), ("loc", model.rpn_model.loc)]
+        if variant != "rpn":
+            branches.append(("mask", model.mask_model.mask))
+        for bn_, br in branches:
+            corr = br.forward_corr(model.zf, search)
+            put(store, "corr_" + bn_, sample(corr))
+            put(store, "zk_" + bn_, sample(br.conv_kernel(model.zf)))
+        store["cls"] = cls.numpy().astype(np.float32)
+        store["loc"] = loc.numpy().astype(np.float32)
+        best = []
+        for b in range(B):
+            bid, dy, dx, pscore = decode_best(cls[b].numpy(), loc[b].numpy())
+            srt = np.sort(pscore)[::-1]
+            best.append((bid, dy, dx, srt[0] - srt[1]))
+        store["best_id"] = np.array([t[0] for t in best], dtype=np.int64)
+        store["best_yx"] = np.array([[t[1], t[2]] for t in best], dtype=np.int64)
+        store["top2_gap"] = np.array([t[3] for t in best], dtype=np.float64)
+        if mask is not None:
+            put(store, "mask", sample(mask, 16384))
+            store["mask_col"] = np.stack(
+                [mask[b, :, best[b][1], best[b][2]].numpy() for b in range(B)]).astype(np.float32)
+        if variant == "sharp":
+            outs = []
+            for b in range(B):
+                f = [t[b:b + 1] for t in model.feature]
+                outs.append(model.refine_model(f, model.corr_feature[b:b + 1],
+                                               pos=(best[b][1], best[b][2]), test=True))
+            store["refine"] = torch.cat(outs).numpy().astype(np.float32)
+            if shared_pos is not None:
+                store["shared_pos"] = np.array(shared_pos, dtype=np.int64)
+                store["refine_shared"] = model.track_refine(tuple(shared_pos)).numpy().astype(np.float32)
+    path = os.path.join(GOLD, "golden_%s.npz" % name)
+    np.savez_compressed(path, **store)
+    print("%-28s %s  best=%s gap=%s  (%.1f KB)" % (
+        name, tuple(store["cls"].shape), store["best_id"], store["top2_gap"], os.path.getsize(path) / 1024.0))
+
+
+def u8(a):
+    return a.astype(np.uint8)
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    os.makedirs(GOLD, exist_ok=True)
+    for fixture in synth.FIXTURES:
+        calibrate(fixture)
+    mix = lambda size, s0: u8(np.concatenate(
+        [synth.image_batch(1, size, stream0=s0), synth.smooth_image_batch(1, size, stream0=s0 + 1)]))
+    run_case("sharp_damped_b2", "sharp", "synthetic_damped", mix(127, 10), mix(255, 10), shared_pos=(3, 20))
+    run_case("sharp_stress_b1", "sharp", "synthetic_stress",
+             u8(synth.smooth_image_batch(1, 127, stream0=20)), u8(synth.smooth_image_batch(1, 255, stream0=20)),
+             shared_pos=(12, 12))
+    run_case("base_damped_b1", "base", "synthetic_damped",
+             u8(synth.smooth_image_batch(1, 127, stream0=30)), u8(synth.smooth_image_batch(1, 255, stream0=30)))
+    run_case("rpn_damped_b1", "rpn", "synthetic_damped",
+             u8(synth.image_batch(1, 127, stream0=40)), u8(synth.image_batch(1, 255, stream0=40)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,321 @@
+"""CPU oracle: numpy restatement of the SiamMask per-frame inference path.
+
+    *** TEST INFRASTRUCTURE ONLY ***
+    Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+    module, and only as the checker.  The product path (siammask_amd/) never imports it
+    and fails loudly when the HIP extension is missing.
+
+What it restates (reference file:line, relative to /root/reference):
+  * modified ResNet-50                 experiments/siammask_sharp/resnet.py:59-103,151-227
+  * ResDownS / ResDown                 experiments/siammask_sharp/custom.py:12-25,58-66
+  * DepthCorr + conv2d_dw_group        models/rpn.py:32-72
+  * UP / MaskCorr                      experiments/siammask_sharp/custom.py:69-96
+  * Refine.forward(test=True)          experiments/siammask_sharp/custom.py:131-154
+  * Custom.template/track/track_mask/track_refine
+                                       experiments/siammask_sharp/custom.py:173-190
+                                       experiments/siammask_base/custom.py:100-112
+                                       experiments/siamrpn_resnet/custom.py:87-93
+The arithmetic itself lives in PyTorch (torch==0.4.1 pinned at requirements.txt:6), a
+third-party dependency that is not under /root/reference; the published semantics of
+nn.Conv2d / BatchNorm2d(eval) / MaxPool2d / ConvTranspose2d / F.pad / F.upsample(nearest)
+are restated below in plain numpy (im2col + matmul, default float64).
+
+Parity pinning: the reference has NO tests or golden vectors for this path (SURVEY.md
+section 4), so this oracle is pinned against outputs of the reference itself, run in this
+container on CPU in float64 (oracle/make_golden.py -> tests/golden/*.npz); the check is
+tests/test_oracle_golden.py.
+
+``QuantOracle`` additionally emulates the rounding points of the fp16 HIP path (fp16
+weights/activations, fp32 accumulate) so that the fp16 kernels can be gated tightly.
+"""
+import numpy as np
+
+BN_EPS = 1e-5  # nn.BatchNorm2d default, used everywhere in the reference
+
+
+# ------------------------------------------------------------------------------------
+# primitive ops (published torch semantics)
+# ------------------------------------------------------------------------------------
+def conv2d(x, w, b=None, stride=1, pad=0, dil=1):
+    """nn.Conv2d forward, NCHW, cross-correlation (no kernel flip), zero padding."""
+    B, C, H, W = x.shape
+    Co, Ci, kh, kw = w.shape
+    assert Ci == C
+    if pad:
+        x = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    Hp, Wp = x.shape[2], x.shape[3]
+    Ho = (Hp - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Wp - dil * (kw - 1) - 1) // stride + 1
+    sB, sC, sH, sW = x.strides
+    cols = np.lib.stride_tricks.as_strided(
+        x, shape=(B, C, kh, kw, Ho, Wo),
+        strides=(sB, sC, sH * dil, sW * dil, sH * stride, sW * stride), writeable=False)
+    cols = cols.reshape(B, C * kh * kw, Ho * Wo)
+    out = np.matmul(w.reshape(Co, -1), cols).reshape(B, Co, Ho, Wo)
+    if b is not None:
+        out = out + b.reshape(1, -1, 1, 1)
+    return out
+
+
+def batchnorm_eval(x, gamma, beta, mean, var):
+    """nn.BatchNorm2d in eval(): y = (x - mean) / sqrt(var + eps) * gamma + beta."""
+    inv = gamma / np.sqrt(var + BN_EPS)
+    return x * inv.reshape(1, -1, 1, 1) + (beta - mean * inv).reshape(1, -1, 1, 1)
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def maxpool_3x3_s2_p1(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (pads with -inf)."""
+    B, C, H, W = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)), constant_values=-np.inf)
+    Ho = (H + 2 - 3) // 2 + 1
+    Wo = (W + 2 - 3) // 2 + 1
+    sB, sC, sH, sW = xp.strides
+    win = np.lib.stride_tricks.as_strided(
+        xp, shape=(B, C, Ho, Wo, 3, 3), strides=(sB, sC, 2 * sH, 2 * sW, sH, sW), writeable=False)
+    return win.max(axis=(4, 5))
+
+
+def upsample_nearest(x, size):
+    """F.upsample(x, size=(s, s)) with the default mode='nearest':
+    src = min(floor(dst * in / out), in - 1)."""
+    H, W = x.shape[2], x.shape[3]
+    iy = np.minimum((np.arange(size) * H) // size, H - 1)
+    ix = np.minimum((np.arange(size) * W) // size, W - 1)
+    return x[:, :, iy][:, :, :, ix]
+
+
+def conv_transpose_1x1_input(x, w, b):
+    """nn.ConvTranspose2d(Cin, Cout, k, stride=k) applied to a 1x1 spatial input:
+    out[b,o,u,v] = sum_i x[b,i] * w[i,o,u,v] + bias[o]."""
+    B = x.shape[0]
+    out = np.einsum("bi,iouv->bouv", x.reshape(B, -1), w)
+    return out + b.reshape(1, -1, 1, 1)
+
+
+def conv2d_dw_group(x, kernel):
+    """models/rpn.py:32-38 — depth-wise valid cross-correlation per (batch, channel):
+    out[b,c,i,j] = sum_{u,v} x[b,c,i+u,j+v] * kernel[b,c,u,v]."""
+    B, C, H, W = x.shape
+    kb, kc, kh, kw = kernel.shape
+    assert (kb, kc) == (B, C), "reference requires template batch == search batch"
+    Ho, Wo = H - kh + 1, W - kw + 1
+    out = np.zeros((B, C, Ho, Wo), dtype=np.result_type(x, kernel))
+    for u in range(kh):
+        for v in range(kw):
+            out += x[:, :, u:u + Ho, v:v + Wo] * kernel[:, :, u:u + 1, v:v + 1]
+    return out
+
+
+# ------------------------------------------------------------------------------------
+# network
+# ------------------------------------------------------------------------------------
+class Oracle(object):
+    """Functional restatement of ``Custom`` for variant in {'rpn','base','sharp'}.
+
+    ``sd`` maps reference state-dict names to numpy arrays.  State carried between calls
+    mirrors the reference instance attributes (zf, feature, search, corr_feature)."""
+
+    def __init__(self, sd, variant="sharp", dtype=np.float64):
+        self.variant = variant
+        self.dtype = dtype
+        self.sd = {k: np.asarray(v).astype(dtype) for k, v in sd.items()
+                   if not k.endswith("num_batches_tracked")}
+        self.zf = None
+        self.feature = None
+        self.search = None
+        self.corr_feature = None
+
+    # -- helpers ---------------------------------------------------------------------
+    def _conv(self, x, name, stride=1, pad=0, dil=1):
+        return conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride, pad, dil)
+
+    def _bn(self, x, name):
+        s = self.sd
+        return batchnorm_eval(x, s[name + ".weight"], s[name + ".bias"],
+                              s[name + ".running_mean"], s[name + ".running_var"])
+
+    # -- ResNet (experiments/siammask_sharp/resnet.py) ----------------------------------
+    def _bottleneck(self, x, p, stride, dil, ds):
+        """Bottleneck.forward, resnet.py:80-103; conv2 padding per :66-72;
+        ds = None | (kernel, stride, pad) of the shortcut conv (_make_layer :184-206)."""
+        pad2 = dil if dil > 1 else 2 - stride
+        out = relu(self._bn(self._conv(x, p + "conv1"), p + "bn1"))
+        out = relu(self._bn(self._conv(out, p + "conv2", stride, pad2, dil), p + "bn2"))
+        out = self._bn(self._conv(out, p + "conv3"), p + "bn3")
+        if ds is not None:
+            k, s, pd = ds
+            residual = self._bn(self._conv(x, p + "downsample.0", s, pd, 1), p + "downsample.1")
+        else:
+            residual = x
+        return relu(out + residual)
+
+    def resnet(self, x):
+        """ResNet.forward, resnet.py:217-227 -> (p0, p1, p2, p3)."""
+        f = "features.features."
+        p0 = relu(self._bn(self._conv(x, f + "conv1", 2, 0), f + "bn1"))      # 7x7 s2 p0 (:154)
+        x = maxpool_3x3_s2_p1(p0)                                             # (:158)
+        # layer1: stride 1, dilation 1, 1x1 shortcut (:159, :188-193)
+        for b in range(3):
+            x = self._bottleneck(x, f + "layer1.%d." % b, 1, 1, (1, 1, 0) if b == 0 else None)
+        p1 = x
+        # layer2: stride 2 -> 3x3 s2 p0 shortcut, conv2 3x3 s2 p0 (:160, :195-206)
+        for b in range(4):
+            x = self._bottleneck(x, f + "layer2.%d." % b, 2 if b == 0 else 1, 1,
+                                 (3, 2, 0) if b == 0 else None)
+        p2 = x
+        # layer3: stride 1 dilation 2 -> block 0 dilation 1 with 3x3 s1 p1 shortcut,
+        # blocks 1..5 dilation 2 (:165, :196-213)
+        for b in range(6):
+            x = self._bottleneck(x, f + "layer3.%d." % b, 1, 1 if b == 0 else 2,
+                                 (3, 1, 1) if b == 0 else None)
+        p3 = x
+        return p0, p1, p2, p3
+
+    def resdown(self, x):
+        """ResDown.forward_all + ResDownS.forward, custom.py:19-25,58-66."""
+        feats = self.resnet(x)
+        d = "features.downsample.downsample."
+        y = self._bn(self._conv(feats[3], d + "0"), d + "1")
+        if y.shape[3] < 20:                       # custom.py:21-24 (template only: 15 < 20)
+            y = y[:, :, 4:-4, 4:-4]
+        return feats, y
+
+    # -- DepthCorr (models/rpn.py:41-72) --------------------------------------------------
+    def _conv_bn_relu(self, x, p):
+        return relu(self._bn(self._conv(x, p + ".0"), p + ".1"))
+
+    def forward_corr(self, p, kernel, search):
+        k = self._conv_bn_relu(kernel, p + "conv_kernel")       # rpn.py:64
+        s = self._conv_bn_relu(search, p + "conv_search")       # rpn.py:65
+        return conv2d_dw_group(s, k)                            # rpn.py:66
+
+    def head(self, p, feature):
+        h = self._conv_bn_relu(feature, p + "head")             # rpn.py:56-59
+        return self._conv(h, p + "head.3")                      # rpn.py:60 (1x1 with bias)
+
+    def depthcorr(self, p, kernel, search):
+        return self.head(p, self.forward_corr(p, kernel, search))   # rpn.py:69-72
+
+    # -- Refine (custom.py:131-154, test=True path) ------------------------------------
+    def _seq2(self, x, p):
+        """nn.Sequential(conv3x3 p1, ReLU, conv3x3 p1, ReLU) of custom.py:102-118."""
+        x = relu(self._conv(x, p + ".0", 1, 1))
+        return relu(self._conv(x, p + ".2", 1, 1))
+
+    def refine(self, f, corr_feature, pos):
+        r = "refine_model."
+        y, x = int(pos[0]), int(pos[1])
+        pz = lambda t, n: np.pad(t, ((0, 0), (0, 0), (n, n), (n, n)))
+        p0 = pz(f[0], 16)[:, :, 4 * y:4 * y + 61, 4 * x:4 * x + 61]        # :133
+        p1 = pz(f[1], 8)[:, :, 2 * y:2 * y + 31, 2 * x:2 * x + 31]         # :134
+        p2 = pz(f[2], 4)[:, :, y:y + 15, x:x + 15]                         # :135
+        p3 = corr_feature[:, :, y, x].reshape(-1, 256, 1, 1)                # :145
+        out = conv_transpose_1x1_input(p3, self.sd[r + "deconv.weight"], self.sd[r + "deconv.bias"])  # :149
+        out = self._conv(upsample_nearest(self._seq2(out, r + "h2") + self._seq2(p2, r + "v2"), 31),
+                         r + "post0", 1, 1)                                 # :150
+        out = self._conv(upsample_nearest(self._seq2(out, r + "h1") + self._seq2(p1, r + "v1"), 61),
+                         r + "post1", 1, 1)                                 # :151
+        out = self._conv(upsample_nearest(self._seq2(out, r + "h0") + self._seq2(p0, r + "v0"), 127),
+                         r + "post2", 1, 1)                                 # :152
+        return out.reshape(-1, 127 * 127)                                   # :153
+
+    # -- Custom surface ----------------------------------------------------------------
+    def template(self, z):
+        """custom.py:173-174."""
+        _, self.zf = self.resdown(np.asarray(z, dtype=self.dtype))
+
+    def track(self, x):
+        """custom.py:176-179 -> (cls [B,10,25,25], loc [B,20,25,25])."""
+        _, search = self.resdown(np.asarray(x, dtype=self.dtype))
+        cls = self.depthcorr("rpn_model.cls.", self.zf, search)
+        loc = self.depthcorr("rpn_model.loc.", self.zf, search)
+        return cls, loc
+
+    def track_mask(self, x):
+        """sharp: custom.py:181-186; base: experiments/siammask_base/custom.py:108-112."""
+        assert self.variant in ("base", "sharp")
+        self.feature, self.search = self.resdown(np.asarray(x, dtype=self.dtype))
+        cls = self.depthcorr("rpn_model.cls.", self.zf, self.search)
+        loc = self.depthcorr("rpn_model.loc.", self.zf, self.search)
+        self.corr_feature = self.forward_corr("mask_model.mask.", self.zf, self.search)
+        pred_mask = self.head("mask_model.mask.", self.corr_feature)
+        return cls, loc, pred_mask
+
+    def track_refine(self, pos):
+        """custom.py:188-190.  ``pos`` = (y, x) shared by the batch (reference semantics) or a
+        [B,2] array of per-item positions (batched-stream extension; equals running the
+        reference once per item)."""
+        assert self.variant == "sharp"
+        pos = np.asarray(pos)
+        if pos.ndim == 1:
+            return self.refine(self.feature, self.corr_feature, pos)
+        outs = []
+        for b in range(pos.shape[0]):
+            f = [t[b:b + 1] for t in self.feature]
+            outs.append(self.refine(f, self.corr_feature[b:b + 1], pos[b]))
+        return np.concatenate(outs, axis=0)
+
+
+# ------------------------------------------------------------------------------------
+# host-side decode used by the parity tests (tools/test.py:205-254), restated
+# ------------------------------------------------------------------------------------
+def generate_anchor(score_size=25, stride=8, ratios=(0.33, 0.5, 1, 2, 3), scales=(8,)):
+    """tools/test.py:113-129 + utils/anchors.py:28-51 (integer-truncated ws/hs)."""
+    anchors = []
+    size = stride * stride
+    for r in ratios:
+        ws = int(np.sqrt(size * 1.0 / r))
+        hs = int(ws * r)
+        for s in scales:
+            anchors.append((ws * s, hs * s))
+    anchor_num = len(anchors)
+    ori = -(score_size // 2) * stride
+    xx, yy = np.meshgrid([ori + stride * dx for dx in range(score_size)],
+                         [ori + stride * dy for dy in range(score_size)])
+    out = np.zeros((anchor_num * score_size * score_size, 4), dtype=np.float32)
+    n = score_size * score_size
+    for a, (w, h) in enumerate(anchors):
+        out[a * n:(a + 1) * n, 0] = xx.flatten()
+        out[a * n:(a + 1) * n, 1] = yy.flatten()
+        out[a * n:(a + 1) * n, 2] = w
+        out[a * n:(a + 1) * n, 3] = h
+    return out
+
+
+def decode_best(cls, loc, target_sz=(60.0, 80.0), scale_x=1.0, penalty_k=0.04,
+                window_influence=0.4, score_size=25):
+    """Per-item restatement of tools/test.py:205-254: softmax foreground score, anchor
+    decode, scale/ratio penalty, cosine window, argmax -> (best_id, delta_y, delta_x, pscore).
+    cls: [10,25,25], loc: [20,25,25] (one item)."""
+    anchor = generate_anchor(score_size)
+    delta = loc.reshape(4, -1).astype(np.float64)
+    sc = cls.reshape(2, -1).astype(np.float64)
+    e = np.exp(sc - sc.max(axis=0, keepdims=True))
+    score = (e / e.sum(axis=0, keepdims=True))[1]
+    delta[0] = delta[0] * anchor[:, 2] + anchor[:, 0]
+    delta[1] = delta[1] * anchor[:, 3] + anchor[:, 1]
+    delta[2] = np.exp(delta[2]) * anchor[:, 2]
+    delta[3] = np.exp(delta[3]) * anchor[:, 3]
+
+    def change(r):
+        return np.maximum(r, 1.0 / r)
+
+    def sz(w, h):
+        pad = (w + h) * 0.5
+        return np.sqrt((w + pad) * (h + pad))
+
+    tw, th = target_sz[0] * scale_x, target_sz[1] * scale_x
+    s_c = change(sz(delta[2], delta[3]) / sz(tw, th))
+    r_c = change((tw / th) / (delta[2] / delta[3]))
+    penalty = np.exp(-(r_c * s_c - 1) * penalty_k)
+    pscore = penalty * score
+    window = np.outer(np.hanning(score_size), np.hanning(score_size))
+    window = np.tile(window.flatten(), 5)
+    pscore = pscore * (1 - window_influence) + window * window_influence
+    best = int(np.argmax(pscore))
+    _, dy, dx = np.unravel_index(best, (5, score_size, score_size))
+    return best, int(dy), int(dx), pscore

@@ -1,0 +1,56 @@
+"""Pin the numpy oracle (oracle/np_oracle.py) against outputs of the reference itself.
+
+The reference has no golden vectors of its own; the fixtures under
+tests/golden/ were produced by oracle/make_golden.py running the reference modules in
+float64 on CPU.  Tolerance: the oracle runs in float64 too, so agreement is at float64
+round-off amplified by the network (<= 1e-9 rel-to-max; fixtures are stored as float32,
+hence the 2e-7 storage floor)."""
+import numpy as np
+import pytest
+
+from oracle.np_oracle import Oracle, decode_best
+from siammask_amd import synth
+from helpers import CASES, load_golden, rel_err, sampled_err
+
+TOL = 5e-7  # float32 storage of the fixtures dominates
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case):
+    g = load_golden(case)
+    variant, fixture = str(g["variant"]), str(g["fixture"])
+    o = Oracle(synth.state_dict(variant, fixture), variant)
+    o.template(g["z_u8"].astype(np.float64))
+    assert rel_err(o.zf, g["zf_full"]) < TOL
+    x = g["x_u8"].astype(np.float64)
+    if variant == "rpn":
+        cls, loc = o.track(x)
+    else:
+        cls, loc, mask = o.track_mask(x)
+        assert sampled_err(g, "mask", mask) < TOL
+        for b in range(x.shape[0]):
+            y_, x_ = g["best_yx"][b]
+            assert rel_err(mask[b, :, y_, x_], g["mask_col"][b]) < TOL
+        assert sampled_err(g, "search", o.search) < TOL
+        assert sampled_err(g, "corr_mask", o.corr_feature) < TOL
+    assert rel_err(cls, g["cls"]) < TOL
+    assert rel_err(loc, g["loc"]) < TOL
+    for b in range(x.shape[0]):
+        bid, dy, dx, _ = decode_best(cls[b], loc[b])
+        assert bid == int(g["best_id"][b])           # bit-exact argmax box index
+        assert (dy, dx) == tuple(int(v) for v in g["best_yx"][b])
+    if variant == "sharp":
+        for n_, f_ in zip(("p0", "p1", "p2", "p3"), o.feature):
+            assert sampled_err(g, n_, f_) < TOL
+        ref = o.track_refine(g["best_yx"])
+        assert rel_err(ref, g["refine"]) < TOL
+        shared = o.track_refine(tuple(int(v) for v in g["shared_pos"]))
+        assert rel_err(shared, g["refine_shared"]) < TOL
+
+
+def test_fixture_is_well_conditioned():
+    """Logits O(1) and an argmax gap far above the fp32 tolerance."""
+    for case in CASES:
+        g = load_golden(case)
+        assert np.abs(g["cls"]).max() < 50 and np.abs(g["loc"]).max() < 50
+        assert g["top2_gap"].min() > 1e-3
