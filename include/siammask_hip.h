@@ -1,0 +1,172 @@
+/*
+ * siammask_hip.h -- C ABI of libsiammask_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (foolwood/SiamMask) has no native layer on its inference path: the path's
+ * arithmetic is dispatched from Python into PyTorch (torch==0.4.1, requirements.txt:6).
+ * This library replaces everything *below* the reference's drop-in boundary
+ *     experiments/siammask_sharp/custom.py:173-190   Custom.template / track / track_mask / track_refine
+ *     experiments/siammask_base/custom.py:100-112    (3-branch variant, 63x63 mask head)
+ *     experiments/siamrpn_resnet/custom.py:87-93     (box-only variant)
+ * with hand-written HIP kernels.  Each entry point cites the reference interface it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross the boundary;
+ *   - every function returns 0 on success, a negative SMK_E* code otherwise, and
+ *     smk_last_error() returns a human readable message for the calling thread;
+ *   - device pointers are raw HIP device addresses (torch: tensor.data_ptr());
+ *   - all device work is enqueued asynchronously on the caller's hipStream_t (passed as
+ *     void*; torch: torch.cuda.current_stream().cuda_stream); nothing synchronises;
+ *   - the caller owns all I/O buffers; the library owns packed weights and the activation
+ *     arena inside the opaque smk_ctx;
+ *   - one ctx per (device, stream of use); not thread-safe, not re-entrant (the reference
+ *     model is stateful in the same way: self.zf / self.feature / self.corr_feature).
+ *   - tensors at the boundary are float32, NCHW, contiguous -- exactly what the reference's
+ *     callers hand over / consume (tools/test.py:155,201-207,257-261).
+ */
+#ifndef SIAMMASK_HIP_H
+#define SIAMMASK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smk_ctx smk_ctx;
+
+/* arithmetic type of activations / weights on the device (accumulation is always fp32) */
+#define SMK_DTYPE_F32 0
+#define SMK_DTYPE_F16 1
+
+/* network variant = which reference experiment's Custom is being replaced */
+#define SMK_VARIANT_RPN   0   /* experiments/siamrpn_resnet/custom.py:81-93  */
+#define SMK_VARIANT_BASE  1   /* experiments/siammask_base/custom.py:93-112   */
+#define SMK_VARIANT_SHARP 2   /* experiments/siammask_sharp/custom.py:162-190 */
+
+/* smk_track flags */
+#define SMK_TRACK_BOX   0     /* Custom.track: cls + loc only                              */
+#define SMK_TRACK_MASK  1     /* Custom.track_mask: also corr_feature (+ 63x63 mask head)  */
+#define SMK_TRACK_NO_MASK_HEAD 2 /* with SMK_TRACK_MASK: skip the 3969-channel mask head
+                                    (its result is never read when track_refine is used,
+                                    tools/test.py:256-258); mask_out may then be NULL      */
+
+/* error codes */
+#define SMK_OK            0
+#define SMK_E_ARG        -1   /* bad argument (null pointer, batch out of range, ...)      */
+#define SMK_E_STATE      -2   /* call order violated (track before template, ...)          */
+#define SMK_E_WEIGHT     -3   /* unknown / missing / mis-shaped weight                     */
+#define SMK_E_HIP        -4   /* a HIP runtime call failed                                 */
+#define SMK_E_NODEVICE   -5   /* no gfx950 device visible                                  */
+
+/* library/ABI version: major<<16 | minor */
+int smk_version(void);
+
+/* message describing the last failure on this thread ("" if none) */
+const char *smk_last_error(void);
+
+/* ---- lifetime ------------------------------------------------------------------------
+ * Replaces: Custom.__init__ + model.eval().to(device)  (tools/test.py:559-569).
+ * max_batch = number of streams tracked in lock-step by this ctx (activation arena size). */
+int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch);
+int smk_destroy(smk_ctx *ctx);
+
+/* ---- weights ---------------------------------------------------------------------------
+ * Replaces: utils/load_helper.py:30-54 load_pretrain -> model.load_state_dict.
+ * `name` is the reference state-dict key (e.g.
+ * "features.features.layer3.0.downsample.0.weight"); `data` is HOST float32, contiguous,
+ * in torch layout (conv: [Cout,Cin,kh,kw]; ConvTranspose2d: [Cin,Cout,kh,kw]).
+ * BatchNorm running statistics are ordinary entries; num_batches_tracked is ignored.
+ * smk_finalize_weights folds BN (eval semantics, eps 1e-5), repacks to the MFMA layout,
+ * uploads, and fails with SMK_E_WEIGHT naming the first missing entry. */
+int smk_set_weight(smk_ctx *ctx, const char *name, const float *data,
+                   const int64_t *shape, int ndim);
+int smk_finalize_weights(smk_ctx *ctx);
+
+/* ---- the four reference methods --------------------------------------------------------
+ * smk_template  <- Custom.template(template)          custom.py:173-174
+ *   z_dev: [B,3,127,127] f32 NCHW, raw 0..255 BGR (tools/test.py:61-64,152-155).
+ *   Caches zf and the three conv_kernel(zf) tensors (models/rpn.py:64) inside ctx.
+ * smk_track     <- Custom.track / Custom.track_mask    custom.py:176-186
+ *   x_dev: [B,3,255,255]; cls_out [B,10,25,25], loc_out [B,20,25,25],
+ *   mask_out [B,3969,25,25] (flags & SMK_TRACK_MASK) -- f32 NCHW device buffers.
+ *   B must equal the template batch (models/rpn.py:33: kernel batch defines the groups).
+ * smk_refine    <- Custom.track_refine(pos)            custom.py:188-190
+ *   pos_yx: B pairs (y,x), 0 <= y,x < 25; host memory if pos_on_device == 0 else device.
+ *   (The reference takes ONE (y,x) for the whole batch; pass it B times for that.)
+ *   out: [B,16129] f32.  Requires a preceding smk_track with SMK_TRACK_MASK. */
+int smk_template(smk_ctx *ctx, const float *z_dev, int batch, void *stream);
+int smk_track(smk_ctx *ctx, const float *x_dev, int batch, int flags,
+              float *cls_out, float *loc_out, float *mask_out, void *stream);
+int smk_refine(smk_ctx *ctx, const int32_t *pos_yx, int pos_on_device, int batch,
+               float *out, void *stream);
+
+/* capture the launch sequences into hipGraphs and replay them (on by default when the
+ * environment variable SMK_GRAPH is not "0"); graphs are keyed on (entry, batch, flags,
+ * I/O pointers), so keep the I/O buffers stable to hit the cache. */
+int smk_set_graph_mode(smk_ctx *ctx, int enable);
+
+/* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the
+ * stream it is launched on (graph replay is bypassed while profiling).  smk_profile_dump
+ * synchronises the device and writes a JSON array, one object per layer id in launch order:
+ *   {"id","kernel","calls","ms" (sum of event durations),"flop","bytes"} where flop/bytes are
+ * the ALGORITHMIC work of those launches (2*M*N*K; tensors read/written once), then resets. */
+int smk_profile(smk_ctx *ctx, int enable);
+int smk_profile_dump(smk_ctx *ctx, char *json_buf, int capacity);
+
+/* read back an internal activation as f32 NCHW into a device buffer (parity tests only).
+ * names: "p0","p1","p2","p3","search","zf","zk","xs","corr","head0"; batch = last batch.
+ * *numel_out receives C*H*W per item; dst may be NULL to query the shape (c,h,w). */
+int smk_debug_read(smk_ctx *ctx, const char *name, float *dst_dev, int *c, int *h, int *w,
+                   void *stream);
+
+/* ---- per-op entry points (unit parity against the oracle; not used by the tools) --------
+ * smk_op_conv2d: y = act(conv2d(x, w) + b [+ res]) on f32 NCHW device tensors, computed by
+ * the same implicit-GEMM MFMA kernel the network uses (algo 0) or by the naive one-thread-
+ * per-output kernel (algo 1).  w: host [Cout,Cin,k,k], b: host [Cout] or NULL,
+ * res: device [B,Cout,Ho,Wo] or NULL (added before the ReLU).
+ * smk_op_dw_xcorr <- models/rpn.py:32-38 conv2d_dw_group: x [B,C,H,W], k [B,C,kh,kw]. */
+/* geometry of one convolution for the per-op entry points; tensors are f32 NCHW at this boundary */
+typedef struct smk_conv_geom {
+    int B, Cin, H, W;          /* input tensor [B,Cin,H,W]                                        */
+    int Cout, k, stride, pad, dil;
+    int relu;                  /* apply ReLU in the epilogue                                      */
+    int res_mode;              /* 0 none, 1 add residual before ReLU, 2 add after ReLU            */
+    int win;                   /* 1: the conv sees the Hl x Wl window of the input whose origin is
+                                  (org_y + pos_y*pos_mul + pos_add, org_x + ...); outside the
+                                  window AND outside the tensor reads as zero (F.pad + slice,
+                                  custom.py:133-135; centre crop custom.py:21-24)                 */
+    int ups;                   /* 1: the conv sees the input nearest-upsampled to Hl x Wl
+                                  (F.upsample, custom.py:150-152)                                 */
+    int Hl, Wl, org_y, org_x, pos_mul, pos_add;
+    int cin_off, cin_len;      /* use channels [cin_off, cin_off+cin_len) (cin_len 0 = all)       */
+} smk_conv_geom;
+
+/* algo: low byte 0 = MFMA kernel, NHWC epilogue; 1 = naive kernel, NHWC epilogue;
+ *                2 = MFMA kernel, NCHW-f32 epilogue; 3 = naive kernel, NCHW-f32 epilogue;
+ *       second byte: tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64.
+ * w_host [Cout,cin_len,k,k], b_host [Cout] or NULL (host); x_dev, res_dev [B,Cout,Ho,Wo],
+ * y_dev (device); pos_host: B (y,x) pairs or NULL.  Synchronises the stream (test helper). */
+int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x_dev,
+                     const float *w_host, const float *b_host, const float *res_dev,
+                     const int32_t *pos_host, float *y_dev, void *stream);
+int smk_op_conv2d(int dtype, int algo, const float *x_dev, int B, int Cin, int H, int W,
+                  const float *w_host, const float *b_host, int Cout, int k, int stride,
+                  int pad, int dil, int relu, const float *res_dev, float *y_dev,
+                  void *stream);
+int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, int C,
+                    int H, int W, int kh, int kw, float *y_dev, void *stream);
+int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W,
+                        float *y_dev, void *stream);
+
+/* host-only (no GPU): y = epilogue(conv(x, w) + b) computed on the HOST by walking the packed
+ * weight matrix with the device kernels' own row/tap decode + gather-offset functions.
+ * Lets the CPU test-suite verify packing order, padding, windows and upsampling.
+ * All pointers are host memory. */
+int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, const float *b,
+                       const float *res, const int32_t *pos, float *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIAMMASK_HIP_H */

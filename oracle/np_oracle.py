@@ -128,6 +128,7 @@ class Oracle(object):
         self.feature = None
         self.search = None
         self.corr_feature = None
+        self.dbg = {}          # intermediates by short name (zk_cls, xs_cls, corr_cls, head0_cls, ...)
 
     # -- helpers ---------------------------------------------------------------------
     def _conv(self, x, name, stride=1, pad=0, dil=1):
@@ -189,12 +190,16 @@ class Oracle(object):
         return relu(self._bn(self._conv(x, p + ".0"), p + ".1"))
 
     def forward_corr(self, p, kernel, search):
+        br = p.rstrip(".").split(".")[-1]
         k = self._conv_bn_relu(kernel, p + "conv_kernel")       # rpn.py:64
         s = self._conv_bn_relu(search, p + "conv_search")       # rpn.py:65
-        return conv2d_dw_group(s, k)                            # rpn.py:66
+        corr = conv2d_dw_group(s, k)                            # rpn.py:66
+        self.dbg["zk_" + br], self.dbg["xs_" + br], self.dbg["corr_" + br] = k, s, corr
+        return corr
 
     def head(self, p, feature):
         h = self._conv_bn_relu(feature, p + "head")             # rpn.py:56-59
+        self.dbg["head0_" + p.rstrip(".").split(".")[-1]] = h
         return self._conv(h, p + "head.3")                      # rpn.py:60 (1x1 with bias)
 
     def depthcorr(self, p, kernel, search):

@@ -1,0 +1,105 @@
+"""ctypes binding of libsiammask_hip.so (the C ABI in include/siammask_hip.h).
+
+``import torch`` happens before ``ctypes.CDLL`` on purpose: torch bundles a HIP runtime with
+the same SONAME (libamdhip64.so.7) as /opt/rocm's, and loading torch first makes the
+dynamic linker resolve the library's dependency to the runtime torch already uses, so that
+streams and device pointers are shared.
+
+The product path has no CPU fallback: if the shared library is missing, loading raises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsiammask_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "half": 1}
+VARIANT = {"rpn": 0, "base": 1, "sharp": 2}
+TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
+
+# every symbol include/siammask_hip.h declares
+SYMBOLS = (
+    "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
+    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_graph_mode",
+    "smk_debug_read", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
+    "smk_op_maxpool3x3s2", "smk_host_conv2d_ex",
+)
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "B", "Cin", "H", "W", "Cout", "k", "stride", "pad", "dil", "relu", "res_mode",
+        "win", "ups", "Hl", "Wl", "org_y", "org_x", "pos_mul", "pos_add", "cin_off", "cin_len")]
+
+
+class SmkError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    out = subprocess.run(["make", "-C", CSRC, "-j", "4"], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, universal_newlines=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise SmkError("building libsiammask_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmkError(
+            "%s is missing: the HIP extension has not been built (run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `make -C siammask_amd/csrc`). There is no "
+            "CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    L.smk_version.restype = ci
+    L.smk_last_error.restype = ctypes.c_char_p
+    L.smk_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci]
+    L.smk_destroy.argtypes = [vp]
+    L.smk_set_weight.argtypes = [vp, ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_int64), ci]
+    L.smk_finalize_weights.argtypes = [vp]
+    L.smk_template.argtypes = [vp, fp, ci, vp]
+    L.smk_track.argtypes = [vp, fp, ci, ci, fp, fp, fp, vp]
+    L.smk_refine.argtypes = [vp, vp, ci, ci, fp, vp]
+    L.smk_set_graph_mode.argtypes = [vp, ci]
+    L.smk_profile.argtypes = [vp, ci]
+    L.smk_profile_dump.argtypes = [vp, ctypes.c_char_p, ci]
+    ip = ctypes.POINTER(ci)
+    L.smk_debug_read.argtypes = [vp, ctypes.c_char_p, fp, ip, ip, ip, vp]
+    gp = ctypes.POINTER(ConvGeom)
+    L.smk_op_conv2d_ex.argtypes = [ci, ci, gp, fp, fp, fp, fp, vp, fp, vp]
+    L.smk_op_conv2d.argtypes = [ci, ci, fp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, ci, fp, fp, vp]
+    L.smk_op_dw_xcorr.argtypes = [ci, fp, fp, ci, ci, ci, ci, ci, ci, fp, vp]
+    L.smk_op_maxpool3x3s2.argtypes = [ci, fp, ci, ci, ci, ci, fp, vp]
+    L.smk_host_conv2d_ex.argtypes = [gp, fp, fp, fp, fp, vp, fp]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("smk_last_error",):
+            fn.restype = ci
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().smk_last_error()
+        raise SmkError("libsiammask_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

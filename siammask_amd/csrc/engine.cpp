@@ -1,0 +1,1102 @@
+// engine.cpp -- host side of libsiammask_hip.so: context, BN folding + weight packing,
+// activation arena, the launch sequences for template / track / refine, hipGraph capture,
+// and the extern "C" ABI declared in include/siammask_hip.h.
+//
+// The network topology restated here (layer names, geometry) follows
+//   experiments/siammask_sharp/resnet.py:59-103,151-227   modified ResNet-50
+//   experiments/siammask_sharp/custom.py:12-25,69-159     ResDownS / UP / MaskCorr / Refine
+//   models/rpn.py:41-72                                    DepthCorr
+// and is cross-checked against the reference state dict by tests/test_spec.py through
+// siammask_amd/spec.py (same names, same shapes).
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <tuple>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/siammask_hip.h"
+#include "smk_kernels.h"
+
+using namespace smk;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SMK_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define CHK(expr)                     \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != 0) return rc_;     \
+    } while (0)
+
+static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+// one part of a (possibly N-fused) convolution as it appears in the reference state dict
+struct ConvPart {
+    std::string w;      // "<name>.weight"
+    std::string bn;     // BatchNorm prefix or ""
+    std::string bias;   // "<name>.bias" or ""
+};
+
+struct PackedConv {
+    void *w = nullptr;       // device [rows][Kpad] dtype
+    float *bias = nullptr;   // device [rows] f32
+    int N = 0;               // real output channels per group
+    int rows = 0;            // total rows (all groups), multiple of NPAD_ALIGN
+    int group_rows = 0;      // rows per group
+    int groups = 1;
+    int Ci = 0, k = 1, K = 0, Kpad = 0;
+};
+
+static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
+
+// host-side packing of ONE weight tensor [Cout][Cin][k][k] (already scaled) into rows of a
+// [rows][Kpad] matrix with K ordered (ky, kx, cin_padded)
+static void pack_rows(std::vector<float> &dst, int row0, int Kpad, const float *w, const double *scale,
+                      int Cout, int Cin, int k, int Ci) {
+    for (int n = 0; n < Cout; ++n)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx) {
+                    const double v = (double)w[(((size_t)n * Cin + ci) * k + ky) * k + kx] * scale[n];
+                    dst[(size_t)(row0 + n) * Kpad + (size_t)(ky * k + kx) * Ci + ci] = (float)v;
+                }
+}
+
+static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, const std::vector<float> &bias,
+                         int dtype) {
+    const size_t n = rows_f32.size();
+    HIPCHK(hipMalloc(&pc.w, n * esize(dtype)));
+    if (dtype == DT_F16) {
+        std::vector<_Float16> h(n);
+        for (size_t i = 0; i < n; ++i) h[i] = (_Float16)rows_f32[i];
+        HIPCHK(hipMemcpy(pc.w, h.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(pc.w, rows_f32.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * 4));
+    HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct Act {
+    void *p = nullptr;
+    int H = 0, W = 0, C = 0;   // C = channel stride
+};
+
+typedef std::tuple<int, int, int, const void *, const void *, const void *, const void *> GraphKey;
+
+struct smk_ctx {
+    int device = 0, dtype = DT_F32, variant = SMK_VARIANT_SHARP, maxB = 1;
+    std::map<std::string, HostTensor> host_w;
+    bool finalized = false;
+    int template_B = 0;       // batch of the cached template (0 = none)
+    int track_B = 0;          // batch of the last track with SMK_TRACK_MASK
+    int last_B = 0, last_S = 0, last_nb = 0;
+    bool graph_mode = false;
+    hipStream_t cap_stream = nullptr;
+    std::map<GraphKey, hipGraphExec_t> graphs;
+
+    // packed convolutions
+    std::map<std::string, PackedConv> conv;   // keyed by short layer id
+    // arena (sized for maxB)
+    std::map<std::string, void *> buf;
+    std::map<std::string, size_t> buf_elems;  // per item
+    int *pos_dev = nullptr;
+
+    // per-launch profiling (smk_profile): HIP events around every kernel, eager mode only
+    bool prof = false;
+    struct ProfRec { std::string id, kernel; double flop, bytes; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof_recs;
+};
+
+static const char *dtname(int dt) { return dt == DT_F16 ? "f16" : "f32"; }
+
+struct ProfScope {
+    smk_ctx *c; hipStream_t s; int idx = -1;
+    ProfScope(smk_ctx *c_, hipStream_t s_, const std::string &id, const std::string &kernel, double flop,
+              double bytes) : c(c_), s(s_) {
+        if (!c->prof) return;
+        smk_ctx::ProfRec r{id, kernel, flop, bytes, nullptr, nullptr};
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        (void)hipEventRecord(r.e0, s);
+        c->prof_recs.push_back(r);
+        idx = (int)c->prof_recs.size() - 1;
+    }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, s); }
+};
+
+static int nbranch(const smk_ctx *c) { return c->variant == SMK_VARIANT_RPN ? 2 : 3; }
+
+static const HostTensor *find_w(const smk_ctx *c, const std::string &name) {
+    auto it = c->host_w.find(name);
+    return it == c->host_w.end() ? nullptr : &it->second;
+}
+
+// fold BN (eval semantics) into per-channel scale/shift, or take the conv bias
+static int fold(const smk_ctx *c, const ConvPart &part, int Cout, std::vector<double> &scale,
+                std::vector<double> &shift) {
+    scale.assign(Cout, 1.0);
+    shift.assign(Cout, 0.0);
+    if (!part.bn.empty()) {
+        const HostTensor *g = find_w(c, part.bn + ".weight"), *b = find_w(c, part.bn + ".bias");
+        const HostTensor *m = find_w(c, part.bn + ".running_mean"), *v = find_w(c, part.bn + ".running_var");
+        if (!g || !b || !m || !v) return fail(SMK_E_WEIGHT, "missing BatchNorm tensors for %s", part.bn.c_str());
+        if ((int)g->data.size() != Cout || (int)b->data.size() != Cout || (int)m->data.size() != Cout ||
+            (int)v->data.size() != Cout)
+            return fail(SMK_E_WEIGHT, "BatchNorm %s has wrong size", part.bn.c_str());
+        for (int i = 0; i < Cout; ++i) {
+            const double inv = (double)g->data[i] / std::sqrt((double)v->data[i] + 1e-5);
+            scale[i] = inv;
+            shift[i] = (double)b->data[i] - (double)m->data[i] * inv;
+        }
+    }
+    if (!part.bias.empty()) {
+        const HostTensor *b = find_w(c, part.bias);
+        if (!b || (int)b->data.size() != Cout) return fail(SMK_E_WEIGHT, "missing/mis-sized %s", part.bias.c_str());
+        for (int i = 0; i < Cout; ++i) shift[i] += (double)b->data[i];
+    }
+    return 0;
+}
+
+// pack `parts` either N-fused (one group, rows concatenated) or as separate groups
+static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPart> &parts, int Cin, int Cout,
+                     int k, bool grouped) {
+    PackedConv pc;
+    pc.Ci = rup(Cin, 8);
+    pc.k = k;
+    pc.K = k * k * pc.Ci;
+    pc.Kpad = rup(pc.K, KPAD_ALIGN);
+    const int np = (int)parts.size();
+    if (grouped) {
+        pc.groups = np;
+        pc.N = Cout;
+        pc.group_rows = rup(Cout, NPAD_ALIGN);
+        pc.rows = pc.group_rows * np;
+    } else {
+        pc.groups = 1;
+        pc.N = Cout * np;
+        pc.group_rows = pc.rows = rup(Cout * np, NPAD_ALIGN);
+    }
+    std::vector<float> rows((size_t)pc.rows * pc.Kpad, 0.f), bias(pc.rows, 0.f);
+    for (int i = 0; i < np; ++i) {
+        const HostTensor *w = find_w(c, parts[i].w);
+        if (!w) return fail(SMK_E_WEIGHT, "missing weight %s", parts[i].w.c_str());
+        if (w->shape.size() != 4 || w->shape[0] != Cout || w->shape[1] != Cin || w->shape[2] != k || w->shape[3] != k)
+            return fail(SMK_E_WEIGHT, "weight %s has wrong shape", parts[i].w.c_str());
+        std::vector<double> scale, shift;
+        CHK(fold(c, parts[i], Cout, scale, shift));
+        const int row0 = grouped ? i * pc.group_rows : i * Cout;
+        pack_rows(rows, row0, pc.Kpad, w->data.data(), scale.data(), Cout, Cin, k, pc.Ci);
+        for (int n = 0; n < Cout; ++n) bias[row0 + n] = (float)shift[n];
+    }
+    CHK(upload_packed(pc, rows, bias, c->dtype));
+    c->conv[id] = pc;
+    return 0;
+}
+
+// refine_model.deconv: ConvTranspose2d(256, 32, 15, 15) on a 1x1 input == GEMM with
+// N = 15*15*32 ordered (ky, kx, co) so that the result is the NHWC tensor [15][15][32]
+static int pack_deconv(smk_ctx *c) {
+    const HostTensor *w = find_w(c, "refine_model.deconv.weight"), *b = find_w(c, "refine_model.deconv.bias");
+    if (!w || !b) return fail(SMK_E_WEIGHT, "missing refine_model.deconv.*");
+    if (w->shape.size() != 4 || w->shape[0] != 256 || w->shape[1] != 32 || w->shape[2] != 15 || w->shape[3] != 15)
+        return fail(SMK_E_WEIGHT, "refine_model.deconv.weight has wrong shape");
+    PackedConv pc;
+    pc.Ci = 256; pc.k = 1; pc.K = 256; pc.Kpad = 256; pc.groups = 1;
+    pc.N = 15 * 15 * 32;
+    pc.group_rows = pc.rows = rup(pc.N, NPAD_ALIGN);
+    std::vector<float> rows((size_t)pc.rows * pc.Kpad, 0.f), bias(pc.rows, 0.f);
+    for (int ci = 0; ci < 256; ++ci)
+        for (int co = 0; co < 32; ++co)
+            for (int p = 0; p < 225; ++p) {
+                const int n = p * 32 + co;
+                rows[(size_t)n * pc.Kpad + ci] = w->data[((size_t)ci * 32 + co) * 225 + p];
+            }
+    for (int p = 0; p < 225; ++p)
+        for (int co = 0; co < 32; ++co) bias[p * 32 + co] = b->data[co];
+    CHK(upload_packed(pc, rows, bias, c->dtype));
+    c->conv["deconv"] = pc;
+    return 0;
+}
+
+static const int STAGE_PLANES[3] = {64, 128, 256};
+static const int STAGE_BLOCKS[3] = {3, 4, 6};
+
+static ConvPart bnpart(const std::string &conv, const std::string &bn) { return ConvPart{conv + ".weight", bn, ""}; }
+static ConvPart biaspart(const std::string &conv) { return ConvPart{conv + ".weight", "", conv + ".bias"}; }
+
+static int build_weights(smk_ctx *c) {
+    const std::string f = "features.features.";
+    CHK(pack_conv(c, "stem", {bnpart(f + "conv1", f + "bn1")}, 3, 64, 7, false));
+    int inplanes = 64;
+    for (int s = 0; s < 3; ++s) {
+        const int planes = STAGE_PLANES[s];
+        for (int b = 0; b < STAGE_BLOCKS[s]; ++b) {
+            char pre[64], id[32];
+            snprintf(pre, sizeof(pre), "%slayer%d.%d.", f.c_str(), s + 1, b);
+            snprintf(id, sizeof(id), "l%d.%d.", s + 1, b);
+            const std::string p = pre, i = id;
+            const int cin = b == 0 ? inplanes : planes * 4;
+            CHK(pack_conv(c, i + "c1", {bnpart(p + "conv1", p + "bn1")}, cin, planes, 1, false));
+            CHK(pack_conv(c, i + "c2", {bnpart(p + "conv2", p + "bn2")}, planes, planes, 3, false));
+            CHK(pack_conv(c, i + "c3", {bnpart(p + "conv3", p + "bn3")}, planes, planes * 4, 1, false));
+            if (b == 0)
+                CHK(pack_conv(c, i + "ds", {bnpart(p + "downsample.0", p + "downsample.1")}, cin, planes * 4,
+                              s == 0 ? 1 : 3, false));
+        }
+        inplanes = planes * 4;
+    }
+    CHK(pack_conv(c, "adjust", {bnpart("features.downsample.downsample.0", "features.downsample.downsample.1")},
+                  1024, 256, 1, false));
+    std::vector<std::string> br = {"rpn_model.cls.", "rpn_model.loc."};
+    if (c->variant != SMK_VARIANT_RPN) br.push_back("mask_model.mask.");
+    std::vector<ConvPart> ck, cs, h0;
+    for (auto &b : br) {
+        ck.push_back(bnpart(b + "conv_kernel.0", b + "conv_kernel.1"));
+        cs.push_back(bnpart(b + "conv_search.0", b + "conv_search.1"));
+        h0.push_back(bnpart(b + "head.0", b + "head.1"));
+    }
+    CHK(pack_conv(c, "conv_kernel", ck, 256, 256, 3, false));   // N-fused: [cls | loc | mask]
+    CHK(pack_conv(c, "conv_search", cs, 256, 256, 3, false));
+    CHK(pack_conv(c, "head0", h0, 256, 256, 1, true));          // grouped: each branch its own input
+    CHK(pack_conv(c, "cls3", {biaspart("rpn_model.cls.head.3")}, 256, 10, 1, false));
+    CHK(pack_conv(c, "loc3", {biaspart("rpn_model.loc.head.3")}, 256, 20, 1, false));
+    if (c->variant != SMK_VARIANT_RPN)
+        CHK(pack_conv(c, "mask3", {biaspart("mask_model.mask.head.3")}, 256, 63 * 63, 1, false));
+    if (c->variant == SMK_VARIANT_SHARP) {
+        struct R { const char *n; int c0, c1, c2; };
+        const R rs[6] = {{"v0", 64, 16, 4}, {"v1", 256, 64, 16}, {"v2", 512, 128, 32},
+                         {"h2", 32, 32, 32}, {"h1", 16, 16, 16}, {"h0", 4, 4, 4}};
+        for (auto &r : rs) {
+            const std::string p = std::string("refine_model.") + r.n;
+            CHK(pack_conv(c, std::string(r.n) + ".0", {biaspart(p + ".0")}, r.c0, r.c1, 3, false));
+            CHK(pack_conv(c, std::string(r.n) + ".2", {biaspart(p + ".2")}, r.c1, r.c2, 3, false));
+        }
+        CHK(pack_conv(c, "post0", {biaspart("refine_model.post0")}, 32, 16, 3, false));
+        CHK(pack_conv(c, "post1", {biaspart("refine_model.post1")}, 16, 4, 3, false));
+        CHK(pack_conv(c, "post2", {biaspart("refine_model.post2")}, 4, 1, 3, false));
+        CHK(pack_deconv(c));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// arena
+// ---------------------------------------------------------------------------------------------
+static int alloc_buf(smk_ctx *c, const char *name, size_t elems_per_item) {
+    void *p = nullptr;
+    const size_t bytes = elems_per_item * (size_t)c->maxB * esize(c->dtype) + 256;
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemset(p, 0, bytes));
+    c->buf[name] = p;
+    c->buf_elems[name] = elems_per_item;
+    return 0;
+}
+
+static int build_arena(smk_ctx *c) {
+    const int nb = nbranch(c);
+    CHK(alloc_buf(c, "xin", 255 * 255 * 8));
+    CHK(alloc_buf(c, "p0", 125 * 125 * 64));
+    CHK(alloc_buf(c, "x1", 63 * 63 * 64));
+    CHK(alloc_buf(c, "t1", 63 * 63 * 128));
+    CHK(alloc_buf(c, "t2", 63 * 63 * 128));
+    CHK(alloc_buf(c, "r", 63 * 63 * 256));
+    CHK(alloc_buf(c, "a", 63 * 63 * 256));
+    CHK(alloc_buf(c, "b", 63 * 63 * 256));
+    CHK(alloc_buf(c, "p1", 63 * 63 * 256));
+    CHK(alloc_buf(c, "p2", 31 * 31 * 512));
+    CHK(alloc_buf(c, "search", 31 * 31 * 256));
+    CHK(alloc_buf(c, "zf", 7 * 7 * 256));
+    CHK(alloc_buf(c, "zk", 5 * 5 * 256 * nb));
+    CHK(alloc_buf(c, "xs", 29 * 29 * 256 * nb));
+    CHK(alloc_buf(c, "corr", 25 * 25 * 256 * nb));
+    CHK(alloc_buf(c, "head0", 25 * 25 * 256 * nb));
+    if (c->variant == SMK_VARIANT_SHARP) {
+        CHK(alloc_buf(c, "rf_d", 15 * 15 * 32));
+        CHK(alloc_buf(c, "rf_h2a", 15 * 15 * 32));
+        CHK(alloc_buf(c, "rf_h2b", 15 * 15 * 32));
+        CHK(alloc_buf(c, "rf_v2a", 15 * 15 * 128));
+        CHK(alloc_buf(c, "rf_s2", 15 * 15 * 32));
+        CHK(alloc_buf(c, "rf_u0", 31 * 31 * 16));
+        CHK(alloc_buf(c, "rf_h1a", 31 * 31 * 16));
+        CHK(alloc_buf(c, "rf_h1b", 31 * 31 * 16));
+        CHK(alloc_buf(c, "rf_v1a", 31 * 31 * 64));
+        CHK(alloc_buf(c, "rf_s1", 31 * 31 * 16));
+        CHK(alloc_buf(c, "rf_u1", 61 * 61 * 8));
+        CHK(alloc_buf(c, "rf_h0a", 61 * 61 * 8));
+        CHK(alloc_buf(c, "rf_h0b", 61 * 61 * 8));
+        CHK(alloc_buf(c, "rf_v0a", 61 * 61 * 16));
+        CHK(alloc_buf(c, "rf_s0", 61 * 61 * 8));
+    }
+    HIPCHK(hipMalloc((void **)&c->pos_dev, sizeof(int) * 2 * c->maxB));
+    HIPCHK(hipMemset(c->pos_dev, 0, sizeof(int) * 2 * c->maxB));
+    return 0;
+}
+
+static Act act(smk_ctx *c, const char *name, int H, int W, int C) {
+    Act a;
+    a.p = c->buf.at(name);
+    a.H = H; a.W = W; a.C = C;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+struct ConvOpt {
+    int stride = 1, pad = 0, dil = 1, relu = 0;
+    const Act *res = nullptr;
+    int res_mode = RES_NONE;
+    int res_coff = 0;
+    int cin_off = 0;          // channel slice of the input
+    int cout_off = 0;
+    int n_override = 0;       // use only the first n rows of a fused pack
+    int groups = 1;
+    // window / upsample view of the input
+    bool win = false;
+    int Hl = 0, Wl = 0, org_y = 0, org_x = 0;
+    const int *pos = nullptr;
+    int pos_mul = 0, pos_add = 0;
+    bool ups = false;
+    // NCHW f32 output
+    float *nchw_out = nullptr;
+    int algo_naive = 0;
+    int tile_code = 0;
+};
+
+static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, const Act *out, int B,
+                       const ConvOpt &o, ConvParams &p) {
+    memset(&p, 0, sizeof(p));
+    p.in = in.p;
+    p.wgt = pc.w;
+    p.bias = pc.bias;
+    p.pos = o.pos;
+    p.B = B;
+    p.Hs = in.H; p.Ws = in.W; p.Cs = in.C;
+    p.cin_off = o.cin_off;
+    p.Ci = pc.Ci;
+    p.Hl = (o.win || o.ups) ? o.Hl : in.H;
+    p.Wl = (o.win || o.ups) ? o.Wl : in.W;
+    p.org_y = o.org_y; p.org_x = o.org_x;
+    p.pos_mul = o.pos_mul; p.pos_add = o.pos_add;
+    p.ups = o.ups ? 1 : 0;
+    p.kh = p.kw = pc.k;
+    p.stride = o.stride; p.pad = o.pad; p.dil = o.dil;
+    p.Ho = (p.Hl + 2 * o.pad - o.dil * (pc.k - 1) - 1) / o.stride + 1;
+    p.Wo = (p.Wl + 2 * o.pad - o.dil * (pc.k - 1) - 1) / o.stride + 1;
+    p.K = pc.K; p.Kpad = pc.Kpad;
+    p.N = o.n_override ? o.n_override : pc.N;
+    p.M = B * p.Ho * p.Wo;
+    p.relu = o.relu;
+    p.groups = o.groups;
+    if (o.groups > 1) {
+        p.g_cin_off = pc.Ci;            // branches sit side by side in the channel dimension
+        p.g_wgt_off = pc.group_rows;
+        p.g_cout_off = pc.group_rows;
+    }
+    if (o.nchw_out) {
+        p.out = o.nchw_out;
+        p.out_mode = OUT_NCHW_F32;
+        p.Nst = rup(p.N, 4);
+    } else {
+        if (!out) return fail(SMK_E_ARG, "conv without output");
+        if (out->H != p.Ho || out->W != p.Wo)
+            return fail(SMK_E_ARG, "internal: conv output %dx%d != buffer %dx%d", p.Ho, p.Wo, out->H, out->W);
+        p.out = out->p;
+        p.out_mode = OUT_NHWC;
+        p.Cos = out->C;
+        p.cout_off = o.cout_off;
+        p.Nst = rup(p.N, 8);
+        if (o.cout_off + (o.groups - 1) * pc.group_rows + p.Nst > out->C)
+            return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
+    }
+    if (o.res) {
+        p.res = o.res->p;
+        p.res_Cs = o.res->C;
+        p.res_coff = o.res_coff;
+        p.res_mode = o.res_mode;
+    }
+    (void)c;
+    return 0;
+}
+
+static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
+    switch (code) {
+        case 1: return TileChoice{128, 128};
+        case 2: return TileChoice{128, 64};
+        case 3: return TileChoice{64, 128};
+        case 4: return TileChoice{64, 64};
+        default: return choose_tile(p, dtype);
+    }
+}
+
+static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, int B, const ConvOpt &o,
+                    hipStream_t s) {
+    auto it = c->conv.find(id);
+    if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", id);
+    ConvParams p;
+    CHK(conv_params(c, it->second, in, out, B, o, p));
+    const TileChoice t = tile_from_code(o.tile_code, p, c->dtype);
+    const int ng = p.groups > 0 ? p.groups : 1;
+    // algorithmic work: 2*M*N*K_real flops; bytes = activations read once + weights + output written once
+    const double kreal = (double)p.kh * p.kw * p.Ci;
+    const double flop = 2.0 * p.M * (double)p.N * kreal * ng;
+    const size_t es = esize(c->dtype);
+    const double in_bytes = (double)B * (p.ups ? p.Hs * p.Ws : (double)p.Hl * p.Wl) * p.Ci * es * ng;
+    const double out_bytes = (double)p.M * p.N * ng * (p.out_mode == OUT_NCHW_F32 ? 4 : es);
+    const double bytes = in_bytes + out_bytes + (double)p.N * kreal * es * ng + (p.res ? (double)p.M * p.N * es : 0.0);
+    char kn[64];
+    snprintf(kn, sizeof(kn), "conv_igemm<%s,%d,%d,%s>", dtname(c->dtype), t.bm, t.bn,
+             p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
+    int rc;
+    {
+        ProfScope ps(c, s, id, o.algo_naive ? "conv_naive" : kn, flop, bytes);
+        rc = o.algo_naive ? launch_conv_naive(p, c->dtype, s) : launch_conv_mfma(p, c->dtype, t, s);
+    }
+    if (rc) return fail(SMK_E_HIP, "launch of conv %s failed: %s", id, hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the network
+// ---------------------------------------------------------------------------------------------
+// modified ResNet-50 + adjust (resnet.py:217-227, custom.py:19-25,58-66) on an S x S input.
+// S=255: leaves p0,p1,p2 (kept for Refine) and "search" [31,31,256];  S=127: leaves "zf" [7,7,256].
+static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s) {
+    const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
+    const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
+    const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
+    Act xin = act(c, "xin", S, S, 8);
+    CvtInParams ci{x, xin.p, B, 3, S, S, 8};
+    {
+        ProfScope ps(c, s, "cvt_in", "cvt_in", 0.0, (double)B * S * S * (3 * 4 + 8 * esize(c->dtype)));
+        if (launch_cvt_in(ci, c->dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    }
+    Act p0 = act(c, "p0", s0, s0, 64);
+    ConvOpt o;
+    o.stride = 2; o.relu = 1;
+    CHK(run_conv(c, "stem", xin, &p0, B, o, s));
+    Act x1 = act(c, "x1", s1, s1, 64);
+    PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1};
+    {
+        ProfScope ps(c, s, "maxpool", "maxpool", 0.0, (double)B * 64 * esize(c->dtype) * (s0 * s0 + s1 * s1));
+        if (launch_maxpool(pp, c->dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");
+    }
+
+    Act cur = x1;
+    int sp = s1;                              // current spatial size
+    for (int st = 0; st < 3; ++st) {
+        const int planes = STAGE_PLANES[st];
+        for (int b = 0; b < STAGE_BLOCKS[st]; ++b) {
+            char idb[32];
+            snprintf(idb, sizeof(idb), "l%d.%d.", st + 1, b);
+            const std::string id = idb;
+            const int stride = (st == 1 && b == 0) ? 2 : 1;
+            const int dil = (st == 2 && b > 0) ? 2 : 1;
+            const int pad2 = dil > 1 ? dil : 2 - stride;
+            const int so = stride == 2 ? s2 : sp;
+            Act t1 = act(c, "t1", sp, sp, planes);
+            Act t2 = act(c, "t2", so, so, planes);
+            ConvOpt o1; o1.relu = 1;
+            CHK(run_conv(c, (id + "c1").c_str(), cur, &t1, B, o1, s));
+            ConvOpt o2; o2.relu = 1; o2.stride = stride; o2.pad = pad2; o2.dil = dil;
+            CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
+            Act res = cur;
+            if (b == 0) {
+                Act r = act(c, "r", so, so, planes * 4);
+                ConvOpt od;
+                if (st == 0) { od.stride = 1; od.pad = 0; }          // 1x1
+                else if (st == 1) { od.stride = 2; od.pad = 0; }     // 3x3 s2 p0
+                else { od.stride = 1; od.pad = 1; }                  // 3x3 s1 p1
+                CHK(run_conv(c, (id + "ds").c_str(), cur, &r, B, od, s));
+                res = r;
+            }
+            const bool last = b == STAGE_BLOCKS[st] - 1;
+            const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : "a") : ((b & 1) ? "b" : "a");
+            if (last && st == 2 && cur.p == c->buf.at("a")) oname = "b";
+            Act out = act(c, oname, so, so, planes * 4);
+            ConvOpt o3; o3.relu = 1; o3.res = &res; o3.res_mode = RES_PRE_RELU;
+            CHK(run_conv(c, (id + "c3").c_str(), t2, &out, B, o3, s));
+            cur = out;
+            sp = so;
+        }
+    }
+    // adjust: 1x1 1024->256 + BN, no ReLU; template (15 < 20): centre crop [4:-4] (custom.py:21-24)
+    ConvOpt oa;
+    if (sp < 20) {
+        Act zf = act(c, "zf", sp - 8, sp - 8, 256);
+        oa.win = true; oa.Hl = oa.Wl = sp - 8; oa.org_y = oa.org_x = 4;
+        CHK(run_conv(c, "adjust", cur, &zf, B, oa, s));
+    } else {
+        Act se = act(c, "search", sp, sp, 256);
+        CHK(run_conv(c, "adjust", cur, &se, B, oa, s));
+    }
+    c->last_B = B; c->last_S = S;
+    return 0;
+}
+
+static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
+    CHK(run_backbone(c, z, B, 127, s));
+    const int nb = nbranch(c);
+    Act zf = act(c, "zf", 7, 7, 256);
+    Act zk = act(c, "zk", 5, 5, 256 * nb);
+    ConvOpt o; o.relu = 1;                       // conv_kernel: 3x3 p0 + BN + ReLU (rpn.py:45-49), all branches fused
+    CHK(run_conv(c, "conv_kernel", zf, &zk, B, o, s));
+    return 0;
+}
+
+static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
+                     hipStream_t s) {
+    CHK(run_backbone(c, x, B, 255, s));
+    const int nbt = nbranch(c);                                   // branches laid out in the buffers
+    const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
+    Act se = act(c, "search", 31, 31, 256);
+    Act xs = act(c, "xs", 29, 29, 256 * nbt);
+    ConvOpt o; o.relu = 1; o.n_override = 256 * nb;               // conv_search x nb as one N-fused GEMM
+    CHK(run_conv(c, "conv_search", se, &xs, B, o, s));
+    Act corr = act(c, "corr", 25, 25, 256 * nbt);
+    XcorrParams xp{xs.p, c->buf.at("zk"), corr.p, B, 29, 29, 5, 5, 25, 25, 256 * nb, 256 * nbt};
+    {
+        // algorithmic bytes per branch-item: read 256*(29*29 + 5*5), write 256*25*25 elements
+        const double xb = (double)B * nb * 256.0 * (29 * 29 + 25 + 625) * esize(c->dtype);
+        ProfScope ps(c, s, "dw_xcorr", "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, xb);
+        if (launch_xcorr(xp, c->dtype, s)) return fail(SMK_E_HIP, "xcorr launch failed");
+    }
+    Act h0 = act(c, "head0", 25, 25, 256 * nbt);
+    ConvOpt oh; oh.relu = 1; oh.groups = nb;                      // head.0 1x1 + BN + ReLU per branch
+    CHK(run_conv(c, "head0", corr, &h0, B, oh, s));
+    ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
+    CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s));
+    ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
+    CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s));
+    if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD)) {
+        ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
+        CHK(run_conv(c, "mask3", h0, nullptr, B, om, s));
+    }
+    c->last_nb = nb;
+    return 0;
+}
+
+// Refine.forward(test=True), custom.py:131-154, with a per-item position
+static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
+    const int *pos = c->pos_dev;
+    Act corr = act(c, "corr", 25, 25, 256 * 3);
+    Act p0 = act(c, "p0", 125, 125, 64), p1 = act(c, "p1", 63, 63, 256), p2 = act(c, "p2", 31, 31, 512);
+    // deconv(corr_feature[:, :, y, x]) -> [15,15,32]            (:145,:149)
+    Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
+    ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
+    CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
+    Act d = act(c, "rf_d", 15, 15, 32);
+    ConvOpt r3; r3.pad = 1; r3.relu = 1;
+    // stage 2 @15x15                                             (:150)
+    Act h2a = act(c, "rf_h2a", 15, 15, 32), h2b = act(c, "rf_h2b", 15, 15, 32);
+    CHK(run_conv(c, "h2.0", d, &h2a, B, r3, s));
+    CHK(run_conv(c, "h2.2", h2a, &h2b, B, r3, s));
+    Act v2a = act(c, "rf_v2a", 15, 15, 128), s2 = act(c, "rf_s2", 15, 15, 32);
+    ConvOpt w2 = r3; w2.win = true; w2.Hl = w2.Wl = 15; w2.pos = pos; w2.pos_mul = 1; w2.pos_add = -4;   // pad 4 (:135)
+    CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
+    ConvOpt a2 = r3; a2.res = &h2b; a2.res_mode = RES_POST_RELU;
+    CHK(run_conv(c, "v2.2", v2a, &s2, B, a2, s));
+    Act u0 = act(c, "rf_u0", 31, 31, 16);
+    ConvOpt pu0; pu0.pad = 1; pu0.ups = true; pu0.Hl = pu0.Wl = 31;
+    CHK(run_conv(c, "post0", s2, &u0, B, pu0, s));
+    // stage 1 @31x31                                             (:151)
+    Act h1a = act(c, "rf_h1a", 31, 31, 16), h1b = act(c, "rf_h1b", 31, 31, 16);
+    CHK(run_conv(c, "h1.0", u0, &h1a, B, r3, s));
+    CHK(run_conv(c, "h1.2", h1a, &h1b, B, r3, s));
+    Act v1a = act(c, "rf_v1a", 31, 31, 64), s1 = act(c, "rf_s1", 31, 31, 16);
+    ConvOpt w1 = r3; w1.win = true; w1.Hl = w1.Wl = 31; w1.pos = pos; w1.pos_mul = 2; w1.pos_add = -8;   // pad 8 (:134)
+    CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
+    ConvOpt a1 = r3; a1.res = &h1b; a1.res_mode = RES_POST_RELU;
+    CHK(run_conv(c, "v1.2", v1a, &s1, B, a1, s));
+    Act u1 = act(c, "rf_u1", 61, 61, 8);
+    ConvOpt pu1; pu1.pad = 1; pu1.ups = true; pu1.Hl = pu1.Wl = 61;
+    CHK(run_conv(c, "post1", s1, &u1, B, pu1, s));
+    // stage 0 @61x61                                             (:152)
+    Act h0a = act(c, "rf_h0a", 61, 61, 8), h0b = act(c, "rf_h0b", 61, 61, 8);
+    CHK(run_conv(c, "h0.0", u1, &h0a, B, r3, s));
+    CHK(run_conv(c, "h0.2", h0a, &h0b, B, r3, s));
+    Act v0a = act(c, "rf_v0a", 61, 61, 16), s0 = act(c, "rf_s0", 61, 61, 8);
+    ConvOpt w0 = r3; w0.win = true; w0.Hl = w0.Wl = 61; w0.pos = pos; w0.pos_mul = 4; w0.pos_add = -16;  // pad 16 (:133)
+    CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
+    ConvOpt a0 = r3; a0.res = &h0b; a0.res_mode = RES_POST_RELU;
+    CHK(run_conv(c, "v0.2", v0a, &s0, B, a0, s));
+    ConvOpt pu2; pu2.pad = 1; pu2.ups = true; pu2.Hl = pu2.Wl = 127; pu2.nchw_out = out;
+    CHK(run_conv(c, "post2", s0, nullptr, B, pu2, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// graph capture / replay
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&body) {
+    if (!c->graph_mode || c->prof) return body(s);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = body(c->cap_stream);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) return fail(SMK_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipGraphExec_t ex = nullptr;
+        e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(SMK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        if (c->graphs.size() > 64) {           // bound the cache
+            for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+            c->graphs.clear();
+        }
+        it = c->graphs.emplace(key, ex).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int smk_version(void) { return (1 << 16) | 0; }
+
+const char *smk_last_error(void) { return g_err.c_str(); }
+
+int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch) {
+    if (!out) return fail(SMK_E_ARG, "smk_create: out is NULL");
+    *out = nullptr;
+    if (dtype != SMK_DTYPE_F32 && dtype != SMK_DTYPE_F16) return fail(SMK_E_ARG, "smk_create: bad dtype %d", dtype);
+    if (variant < SMK_VARIANT_RPN || variant > SMK_VARIANT_SHARP) return fail(SMK_E_ARG, "smk_create: bad variant %d", variant);
+    if (max_batch < 1 || max_batch > 1024) return fail(SMK_E_ARG, "smk_create: max_batch %d out of range", max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SMK_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(SMK_E_ARG, "smk_create: device %d of %d", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SMK_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    std::unique_ptr<smk_ctx> c(new smk_ctx);
+    c->device = device; c->dtype = dtype; c->variant = variant; c->maxB = max_batch;
+    const char *g = getenv("SMK_GRAPH");
+    c->graph_mode = g && strcmp(g, "0") != 0;
+    int rc = build_arena(c.get());
+    if (rc) return rc;
+    *out = c.release();
+    return 0;
+}
+
+int smk_destroy(smk_ctx *c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    for (auto &kv : c->buf) hipFree(kv.second);
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    if (c->pos_dev) hipFree(c->pos_dev);
+    delete c;
+    return 0;
+}
+
+int smk_set_weight(smk_ctx *c, const char *name, const float *data, const int64_t *shape, int ndim) {
+    if (!c || !name || (!data && ndim > 0)) return fail(SMK_E_ARG, "smk_set_weight: null argument");
+    if (ndim < 0 || ndim > 4) return fail(SMK_E_ARG, "smk_set_weight(%s): ndim %d", name, ndim);
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(SMK_E_ARG, "smk_set_weight(%s): negative dim", name);
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data, data + n);
+    c->host_w[name] = std::move(t);
+    c->finalized = false;
+    return 0;
+}
+
+int smk_finalize_weights(smk_ctx *c) {
+    if (!c) return fail(SMK_E_ARG, "smk_finalize_weights: ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    c->conv.clear();
+    int rc = build_weights(c);
+    if (rc) return rc;
+    c->finalized = true;
+    c->template_B = 0;
+    c->track_B = 0;
+    return 0;
+}
+
+int smk_set_graph_mode(smk_ctx *c, int enable) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    c->graph_mode = enable != 0;
+    return 0;
+}
+
+int smk_template(smk_ctx *c, const float *z, int B, void *stream) {
+    if (!c || !z) return fail(SMK_E_ARG, "smk_template: null argument");
+    if (!c->finalized) return fail(SMK_E_STATE, "smk_template: weights not finalized");
+    if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_template: batch %d not in [1,%d]", B, c->maxB);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    GraphKey key{0, B, 0, z, nullptr, nullptr, nullptr};
+    int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_template(c, z, B, st); });
+    if (rc) return rc;
+    c->template_B = B;
+    c->track_B = 0;
+    return 0;
+}
+
+int smk_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask, void *stream) {
+    if (!c || !x || !cls || !loc) return fail(SMK_E_ARG, "smk_track: null argument");
+    if (!c->finalized) return fail(SMK_E_STATE, "smk_track: weights not finalized");
+    if (c->template_B == 0) return fail(SMK_E_STATE, "smk_track: smk_template has not been called");
+    if (B != c->template_B)
+        return fail(SMK_E_ARG, "smk_track: batch %d != template batch %d (models/rpn.py:33 requires equality)", B,
+                    c->template_B);
+    if ((flags & SMK_TRACK_MASK) && c->variant == SMK_VARIANT_RPN)
+        return fail(SMK_E_ARG, "smk_track: the rpn variant has no mask branch");
+    if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) && !mask)
+        return fail(SMK_E_ARG, "smk_track: mask_out is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    GraphKey key{1, B, flags, x, cls, loc, mask};
+    int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_track(c, x, B, flags, cls, loc, mask, st); });
+    if (rc) return rc;
+    c->track_B = (flags & SMK_TRACK_MASK) ? B : 0;
+    return 0;
+}
+
+int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out, void *stream) {
+    if (!c || !pos || !out) return fail(SMK_E_ARG, "smk_refine: null argument");
+    if (c->variant != SMK_VARIANT_SHARP) return fail(SMK_E_ARG, "smk_refine: only the sharp variant has a Refine module");
+    if (c->track_B == 0) return fail(SMK_E_STATE, "smk_refine: needs a preceding smk_track with SMK_TRACK_MASK");
+    if (B != c->track_B) return fail(SMK_E_ARG, "smk_refine: batch %d != tracked batch %d", B, c->track_B);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!on_device) {
+        for (int i = 0; i < 2 * B; ++i)
+            if (pos[i] < 0 || pos[i] >= 25) return fail(SMK_E_ARG, "smk_refine: pos[%d]=%d outside [0,25)", i, pos[i]);
+        HIPCHK(hipMemcpyAsync(c->pos_dev, pos, sizeof(int) * 2 * B, hipMemcpyHostToDevice, s));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->pos_dev, pos, sizeof(int) * 2 * B, hipMemcpyDeviceToDevice, s));
+    }
+    GraphKey key{2, B, 0, out, nullptr, nullptr, nullptr};
+    return run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_refine(c, B, out, st); });
+}
+
+int smk_profile(smk_ctx *c, int enable) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    c->prof_recs.clear();
+    c->prof = enable != 0;
+    return 0;
+}
+
+int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
+    if (!c || !buf || cap < 64) return fail(SMK_E_ARG, "smk_profile_dump: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    struct Agg { std::string kernel; double ms = 0, flop = 0, bytes = 0; int calls = 0; };
+    std::vector<std::pair<std::string, Agg>> order;
+    std::map<std::string, size_t> idx;
+    for (auto &r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        auto it = idx.find(r.id);
+        if (it == idx.end()) { idx[r.id] = order.size(); order.push_back({r.id, Agg()}); it = idx.find(r.id); }
+        Agg &a = order[it->second].second;
+        a.kernel = r.kernel; a.ms += ms; a.flop += r.flop; a.bytes += r.bytes; a.calls++;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    c->prof_recs.clear();
+    std::string js = "[";
+    for (size_t i = 0; i < order.size(); ++i) {
+        char line[512];
+        const Agg &a = order[i].second;
+        snprintf(line, sizeof(line), "%s{\"id\":\"%s\",\"kernel\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flop\":%.6e,\"bytes\":%.6e}",
+                 i ? "," : "", order[i].first.c_str(), a.kernel.c_str(), a.calls, a.ms, a.flop, a.bytes);
+        js += line;
+    }
+    js += "]";
+    if ((int)js.size() + 1 > cap) return fail(SMK_E_ARG, "smk_profile_dump: buffer too small (%zu needed)", js.size() + 1);
+    memcpy(buf, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int *W, void *stream) {
+    if (!c || !name) return fail(SMK_E_ARG, "smk_debug_read: null argument");
+    const int nbt = nbranch(c);
+    const int S = c->last_S ? c->last_S : 255;
+    const int s0 = (S - 7) / 2 + 1, s1 = (s0 + 2 - 3) / 2 + 1, s2 = (s1 - 3) / 2 + 1;
+    struct E { const char *n, *b; int h, w, cs, cn; };
+    const E tab[] = {
+        {"p0", "p0", s0, s0, 64, 64}, {"p1", "p1", s1, s1, 256, 256}, {"p2", "p2", s2, s2, 512, 512},
+        {"search", "search", 31, 31, 256, 256}, {"zf", "zf", 7, 7, 256, 256},
+        {"zk", "zk", 5, 5, 256 * nbt, 256 * nbt}, {"xs", "xs", 29, 29, 256 * nbt, 256 * nbt},
+        {"corr", "corr", 25, 25, 256 * nbt, 256 * nbt}, {"head0", "head0", 25, 25, 256 * nbt, 256 * nbt},
+    };
+    for (auto &e : tab)
+        if (!strcmp(e.n, name)) {
+            if (C) *C = e.cn;
+            if (H) *H = e.h;
+            if (W) *W = e.w;
+            if (!dst) return 0;
+            if (c->last_B < 1) return fail(SMK_E_STATE, "smk_debug_read: nothing has run yet");
+            CvtOutParams p{c->buf.at(e.b), dst, c->last_B, e.cn, e.h, e.w, e.cs, 0};
+            if (launch_cvt_out(p, c->dtype, stream)) return fail(SMK_E_HIP, "cvt_out launch failed");
+            return 0;
+        }
+    return fail(SMK_E_ARG, "smk_debug_read: unknown tensor %s", name);
+}
+
+// ---- per-op entry points -------------------------------------------------------------------
+struct TmpBufs {
+    std::vector<void *> v;
+    ~TmpBufs() { for (void *p : v) hipFree(p); }
+    int alloc(void **p, size_t bytes) {
+        HIPCHK(hipMalloc(p, bytes + 256));
+        HIPCHK(hipMemset(*p, 0, bytes + 256));
+        v.push_back(*p);
+        return 0;
+    }
+};
+
+static int fill_geom(const smk_conv_geom *g, PackedConv &pc, Act &in, ConvOpt &o, int &Ho, int &Wo) {
+    const int cin_len = g->cin_len > 0 ? g->cin_len : g->Cin;
+    pc.Ci = rup(cin_len, 8);
+    pc.k = g->k;
+    pc.K = g->k * g->k * pc.Ci;
+    pc.Kpad = rup(pc.K, KPAD_ALIGN);
+    pc.groups = 1;
+    pc.N = g->Cout;
+    pc.group_rows = pc.rows = rup(g->Cout, NPAD_ALIGN);
+    in.H = g->H; in.W = g->W; in.C = rup(g->Cin, 8);
+    o.stride = g->stride; o.pad = g->pad; o.dil = g->dil; o.relu = g->relu;
+    o.cin_off = g->cin_off;
+    o.win = g->win != 0; o.ups = g->ups != 0;
+    o.Hl = g->Hl; o.Wl = g->Wl; o.org_y = g->org_y; o.org_x = g->org_x;
+    o.pos_mul = g->pos_mul; o.pos_add = g->pos_add;
+    const int Hl = (o.win || o.ups) ? g->Hl : g->H, Wl = (o.win || o.ups) ? g->Wl : g->W;
+    Ho = (Hl + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+    Wo = (Wl + 2 * g->pad - g->dil * (g->k - 1) - 1) / g->stride + 1;
+    if (Ho < 1 || Wo < 1) return fail(SMK_E_ARG, "conv geometry gives empty output");
+    if (g->cin_off % 8 != 0) return fail(SMK_E_ARG, "cin_off must be a multiple of 8");
+    if (g->cin_off + cin_len > g->Cin) return fail(SMK_E_ARG, "channel slice out of range");
+    return 0;
+}
+
+static void pack_host(const smk_conv_geom *g, const PackedConv &pc, const float *w, const float *b,
+                      std::vector<float> &rows, std::vector<float> &bias) {
+    const int cin_len = g->cin_len > 0 ? g->cin_len : g->Cin;
+    rows.assign((size_t)pc.rows * pc.Kpad, 0.f);
+    bias.assign(pc.rows, 0.f);
+    std::vector<double> one(g->Cout, 1.0);
+    pack_rows(rows, 0, pc.Kpad, w, one.data(), g->Cout, cin_len, g->k, pc.Ci);
+    if (b) for (int n = 0; n < g->Cout; ++n) bias[n] = b[n];
+}
+
+int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x_dev, const float *w_host,
+                     const float *b_host, const float *res_dev, const int32_t *pos_host, float *y_dev,
+                     void *stream) {
+    if (!g || !x_dev || !w_host || !y_dev) return fail(SMK_E_ARG, "smk_op_conv2d_ex: null argument");
+    if (dtype != DT_F32 && dtype != DT_F16) return fail(SMK_E_ARG, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    PackedConv pc; Act in; ConvOpt o; int Ho, Wo;
+    CHK(fill_geom(g, pc, in, o, Ho, Wo));
+    std::vector<float> rows, bias;
+    pack_host(g, pc, w_host, b_host, rows, bias);
+    CHK(upload_packed(pc, rows, bias, dtype));
+    TmpBufs tmp;
+    tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
+    const size_t es = esize(dtype);
+    CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
+    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C};
+    if (launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    int *pos_dev = nullptr;
+    if (pos_host) {
+        CHK(tmp.alloc((void **)&pos_dev, sizeof(int) * 2 * g->B));
+        HIPCHK(hipMemcpyAsync(pos_dev, pos_host, sizeof(int) * 2 * g->B, hipMemcpyHostToDevice, s));
+        o.pos = pos_dev;
+    }
+    const int mode = algo & 0xff;
+    o.tile_code = (algo >> 8) & 0xff;
+    o.algo_naive = (mode == 1 || mode == 3);
+    const bool nchw = (mode == 2 || mode == 3);
+    Act out, res;
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8);
+    if (res_dev && g->res_mode) {
+        if (nchw) return fail(SMK_E_ARG, "residual is not supported with the NCHW epilogue");
+        res = out;
+        CHK(tmp.alloc(&res.p, (size_t)g->B * Ho * Wo * out.C * es));
+        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, out.C};
+        if (launch_cvt_in(cr, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+        o.res = &res; o.res_mode = g->res_mode;
+    }
+    smk_ctx fake;
+    fake.dtype = dtype;
+    ConvParams p;
+    if (nchw) {
+        o.nchw_out = y_dev;
+        CHK(conv_params(&fake, pc, in, nullptr, g->B, o, p));
+    } else {
+        CHK(tmp.alloc(&out.p, (size_t)g->B * Ho * Wo * out.C * es));
+        CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
+    }
+    int rc = o.algo_naive ? launch_conv_naive(p, dtype, s)
+                          : launch_conv_mfma(p, dtype, tile_from_code(o.tile_code, p, dtype), s);
+    if (rc) return fail(SMK_E_HIP, "conv launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!nchw) {
+        CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0};
+        if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int smk_op_conv2d(int dtype, int algo, const float *x_dev, int B, int Cin, int H, int W, const float *w_host,
+                  const float *b_host, int Cout, int k, int stride, int pad, int dil, int relu,
+                  const float *res_dev, float *y_dev, void *stream) {
+    smk_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.k = k; g.stride = stride; g.pad = pad; g.dil = dil;
+    g.relu = relu; g.res_mode = res_dev ? RES_PRE_RELU : RES_NONE;
+    return smk_op_conv2d_ex(dtype, algo, &g, x_dev, w_host, b_host, res_dev, nullptr, y_dev, stream);
+}
+
+int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, int C, int H, int W, int kh, int kw,
+                    float *y_dev, void *stream) {
+    if (!x_dev || !k_dev || !y_dev) return fail(SMK_E_ARG, "smk_op_dw_xcorr: null argument");
+    if (C % 64 != 0) return fail(SMK_E_ARG, "smk_op_dw_xcorr: C must be a multiple of 64");
+    if (kh > 5 || kw > 5 || kh > H || kw > W || (W - kw + 1 + 1) / 2 > 13)
+        return fail(SMK_E_ARG, "smk_op_dw_xcorr: unsupported geometry");
+    hipStream_t s = (hipStream_t)stream;
+    TmpBufs tmp;
+    const size_t es = esize(dtype);
+    const int Ho = H - kh + 1, Wo = W - kw + 1;
+    void *x, *k, *y;
+    CHK(tmp.alloc(&x, (size_t)B * H * W * C * es));
+    CHK(tmp.alloc(&k, (size_t)B * kh * kw * C * es));
+    CHK(tmp.alloc(&y, (size_t)B * Ho * Wo * C * es));
+    CvtInParams cx{x_dev, x, B, C, H, W, C}, ck{k_dev, k, B, C, kh, kw, C};
+    if (launch_cvt_in(cx, dtype, s) || launch_cvt_in(ck, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    XcorrParams xp{x, k, y, B, H, W, kh, kw, Ho, Wo, C, C};
+    if (launch_xcorr(xp, dtype, s)) return fail(SMK_E_HIP, "xcorr launch failed");
+    CvtOutParams co{y, y_dev, B, C, Ho, Wo, C, 0};
+    if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W, float *y_dev, void *stream) {
+    if (!x_dev || !y_dev) return fail(SMK_E_ARG, "smk_op_maxpool3x3s2: null argument");
+    if (C % 8 != 0) return fail(SMK_E_ARG, "smk_op_maxpool3x3s2: C must be a multiple of 8");
+    hipStream_t s = (hipStream_t)stream;
+    TmpBufs tmp;
+    const size_t es = esize(dtype);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    void *x, *y;
+    CHK(tmp.alloc(&x, (size_t)B * H * W * C * es));
+    CHK(tmp.alloc(&y, (size_t)B * Ho * Wo * C * es));
+    CvtInParams cx{x_dev, x, B, C, H, W, C};
+    if (launch_cvt_in(cx, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    PoolParams pp{x, y, B, H, W, C, Ho, Wo};
+    if (launch_maxpool(pp, dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");
+    CvtOutParams co{y, y_dev, B, C, Ho, Wo, C, 0};
+    if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// host-only walk of the packed matrix + the kernels' gather function (no GPU needed)
+int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, const float *b, const float *res,
+                       const int32_t *pos, float *y) {
+    if (!g || !x || !w || !y) return fail(SMK_E_ARG, "smk_host_conv2d_ex: null argument");
+    PackedConv pc; Act in; ConvOpt o; int Ho, Wo;
+    CHK(fill_geom(g, pc, in, o, Ho, Wo));
+    std::vector<float> rows, bias;
+    pack_host(g, pc, w, b, rows, bias);
+    // NCHW -> NHWC (channel padded) on the host, mirroring cvt_in_kernel
+    std::vector<float> xin((size_t)g->B * g->H * g->W * in.C, 0.f);
+    for (int bb = 0; bb < g->B; ++bb)
+        for (int c = 0; c < g->Cin; ++c)
+            for (int yy = 0; yy < g->H; ++yy)
+                for (int xx = 0; xx < g->W; ++xx)
+                    xin[(((size_t)bb * g->H + yy) * g->W + xx) * in.C + c] =
+                        x[(((size_t)bb * g->Cin + c) * g->H + yy) * g->W + xx];
+    in.p = xin.data();
+    pc.w = rows.data();
+    pc.bias = bias.data();
+    o.pos = pos;
+    Act out;
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8);
+    std::vector<float> obuf((size_t)g->B * Ho * Wo * out.C, 0.f);
+    out.p = obuf.data();
+    smk_ctx fake;
+    ConvParams p;
+    CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
+    for (int m = 0; m < p.M; ++m) {
+        const RowInfo r = row_info(p, m, p.pos);
+        for (int n = 0; n < g->Cout; ++n) {
+            double acc = 0.0;
+            for (int kvec = 0; kvec < p.K; kvec += 4) {
+                const KDecode d = decode_k(kvec, p.Ci, p.kw);
+                const long off = gather_offset(p, r, d, p.cin_off);
+                if (off < 0) continue;
+                for (int e = 0; e < 4; ++e) acc += (double)xin[off + e] * (double)rows[(size_t)n * p.Kpad + kvec + e];
+            }
+            double v = acc + bias[n];
+            const int hw = Ho * Wo, bb = m / hw, ps = m - bb * hw;
+            const double rv = (res && g->res_mode) ? res[((size_t)bb * g->Cout + n) * hw + ps] : 0.0;
+            if (g->res_mode == RES_PRE_RELU) v += rv;
+            if (g->relu) v = v > 0 ? v : 0;
+            if (g->res_mode == RES_POST_RELU) v += rv;
+            y[((size_t)bb * g->Cout + n) * hw + ps] = (float)v;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+// misc_kernels.hip -- HBM-bound kernels of the SiamMask path (gfx950):
+//   * dw_xcorr   : depth-wise cross-correlation, models/rpn.py:32-38 (conv2d_dw_group)
+//   * maxpool    : nn.MaxPool2d(3, 2, 1), experiments/siammask_sharp/resnet.py:158
+//   * cvt_in/out : NCHW f32 <-> NHWC dtype at the drop-in boundary
+#include <hip/hip_runtime.h>
+#include "smk_kernels.h"
+
+namespace smk {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct P2;   // a pair of channels
+template <> struct P2<float> {
+    static __device__ inline floatx2 ld(const float *p) { return *(const floatx2 *)p; }
+    static __device__ inline void st(float *p, floatx2 v) { *(floatx2 *)p = v; }
+};
+template <> struct P2<_Float16> {
+    static __device__ inline floatx2 ld(const _Float16 *p) {
+        half2_t h = *(const half2_t *)p;
+        floatx2 v = {(float)h[0], (float)h[1]};
+        return v;
+    }
+    static __device__ inline void st(_Float16 *p, floatx2 v) {
+        half2_t h = {(_Float16)v[0], (_Float16)v[1]};
+        *(half2_t *)p = h;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// dw_xcorr: out[b,i,j,c] = sum_{u,v} x[b,i+u,j+v,c] * k[b,u,v,c]        (NHWC, no flip, valid)
+//
+// Channels sit on lanes (NHWC), so every dot product is lane-local: no cross-lane reduction
+// is needed and every global access is a contiguous 128/256-byte run of 64 channels.
+// Workgroup = (band of XC_BR output rows) x (64 channels) x (batch item): the (BR+kh-1) input
+// rows of that channel chunk and the kh*kw taps are staged in LDS with 16-byte coalesced loads;
+// each thread owns a channel pair and one half-row strip of outputs and slides the kw-wide
+// window along x in registers (each staged value is read from LDS once per tap row).
+// ------------------------------------------------------------------------------------------
+constexpr int XC_CH = 64;      // channels per workgroup
+constexpr int XC_BR = 5;       // output rows per workgroup
+constexpr int XC_SW = 13;      // max outputs per thread strip (half of a 25-wide row)
+constexpr int XC_KMAX = 5;     // max taps per row
+constexpr int XC_THREADS = 32 * XC_BR * 2;
+
+template <typename T>
+__global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    constexpr int VE = 16 / (int)sizeof(T);
+    constexpr int VPP = XC_CH / VE;                 // 16-byte vectors per pixel chunk
+    const int band = blockIdx.x, c0 = blockIdx.y * XC_CH, b = blockIdx.z;
+    const int i0 = band * XC_BR;
+    const int rows_out = min(XC_BR, p.Ho - i0);
+    const int rows_in = rows_out + p.kh - 1;
+    T *sx = (T *)xsm;                                // [rows_in][W][64]
+    T *sk = sx + (XC_BR + XC_KMAX - 1) * p.W * XC_CH; // [kh*kw][64]
+    const T *x = (const T *)p.x;
+    const T *k = (const T *)p.k;
+
+    const int nvx = rows_in * p.W * VPP;
+    for (int v = threadIdx.x; v < nvx; v += XC_THREADS) {
+        const int pix = v / VPP, q = v - pix * VPP;
+        const int r = pix / p.W, col = pix - r * p.W;
+        const size_t g = ((size_t)(b * p.H + i0 + r) * p.W + col) * p.Cs + c0 + q * VE;
+        *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = *(const uint4 *)(x + g);
+    }
+    const int nvk = p.kh * p.kw * VPP;
+    for (int v = threadIdx.x; v < nvk; v += XC_THREADS) {
+        const int tap = v / VPP, q = v - tap * VPP;
+        const size_t g = ((size_t)b * p.kh * p.kw + tap) * p.Cs + c0 + q * VE;
+        *(uint4 *)(sk + (size_t)tap * XC_CH + q * VE) = *(const uint4 *)(k + g);
+    }
+    __syncthreads();
+
+    const int cp = threadIdx.x & 31;                 // channel pair
+    const int strip = threadIdx.x >> 5;              // 0 .. 2*BR-1
+    const int ri = strip >> 1, half = strip & 1;
+    if (ri >= rows_out) return;
+    const int wfirst = (p.Wo + 1) / 2;               // 13 of 25
+    const int j0 = half ? wfirst : 0;
+    const int jn = half ? p.Wo - wfirst : wfirst;    // outputs in this strip (<= XC_SW)
+
+    floatx2 acc[XC_SW];
+#pragma unroll
+    for (int j = 0; j < XC_SW; ++j) acc[j] = floatx2{0.f, 0.f};
+
+    for (int u = 0; u < p.kh; ++u) {
+        floatx2 tap[XC_KMAX];
+#pragma unroll
+        for (int v = 0; v < XC_KMAX; ++v)
+            tap[v] = v < p.kw ? P2<T>::ld(sk + (size_t)(u * p.kw + v) * XC_CH + cp * 2) : floatx2{0.f, 0.f};
+        const T *srow = sx + (size_t)((ri + u) * p.W + j0) * XC_CH + cp * 2;
+#pragma unroll
+        for (int t = 0; t < XC_SW + XC_KMAX - 1; ++t) {
+            // input column j0 + t contributes to outputs jj = t - v, v = 0..kw-1
+            floatx2 xv = floatx2{0.f, 0.f};
+            if (t < jn + p.kw - 1) xv = P2<T>::ld(srow + (size_t)t * XC_CH);
+#pragma unroll
+            for (int v = 0; v < XC_KMAX; ++v) {
+                const int jj = t - v;
+                if (jj >= 0 && jj < XC_SW) {
+                    acc[jj][0] = fmaf(xv[0], tap[v][0], acc[jj][0]);
+                    acc[jj][1] = fmaf(xv[1], tap[v][1], acc[jj][1]);
+                }
+            }
+        }
+    }
+    T *out = (T *)p.out;
+#pragma unroll
+    for (int j = 0; j < XC_SW; ++j)
+        if (j < jn) {
+            const size_t g = ((size_t)(b * p.Ho + i0 + ri) * p.Wo + j0 + j) * p.Cs + c0 + cp * 2;
+            P2<T>::st(out + g, acc[j]);
+        }
+}
+
+int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
+    if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % XC_CH != 0) return -1;
+    const int bands = (p.Ho + XC_BR - 1) / XC_BR;
+    dim3 grid(bands, p.C / XC_CH, p.B);
+    const size_t esz = dtype == DT_F16 ? 2 : 4;
+    const size_t lds = ((size_t)(XC_BR + XC_KMAX - 1) * p.W + XC_KMAX * XC_KMAX) * XC_CH * esz;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_F16) hipLaunchKernelGGL(dw_xcorr_kernel<_Float16>, grid, dim3(XC_THREADS), lds, s, p);
+    else hipLaunchKernelGGL(dw_xcorr_kernel<float>, grid, dim3(XC_THREADS), lds, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ------------------------------------------------------------------------------------------
+// maxpool 3x3 stride 2 pad 1 (pads with -inf), NHWC, one 16-byte channel vector per thread
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_kernel(const PoolParams p) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int cv = p.C / VE;
+    const long total = (long)p.B * p.Ho * p.Wo * cv;
+    const T *in = (const T *)p.in;
+    T *out = (T *)p.out;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cv);
+        long t = idx / cv;
+        const int ox = (int)(t % p.Wo); t /= p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        vec_t m;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) m[e] = (T)(-65504.0f);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const vec_t v = *(const vec_t *)(in + ((size_t)(b * p.H + iy) * p.W + ix) * p.C + q * VE);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *(vec_t *)(out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.C + q * VE) = m;
+    }
+}
+
+int launch_maxpool(const PoolParams &p, int dtype, void *stream) {
+    const int ve = dtype == DT_F16 ? 8 : 4;
+    const long total = (long)p.B * p.Ho * p.Wo * (p.C / ve);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_F16) hipLaunchKernelGGL(maxpool_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ------------------------------------------------------------------------------------------
+// boundary layout conversion: NCHW f32 -> NHWC dtype (channels zero padded to Cpad)
+// one thread per (pixel, 8-channel chunk); for the network input (C=3, Cpad=8) that is one
+// thread per pixel with plane-coalesced reads and a 16/32-byte write.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cvt_in_kernel(const CvtInParams p) {
+    const int chunks = p.Cpad / 8;
+    const long hw = (long)p.H * p.W;
+    const long total = (long)p.B * hw * chunks;
+    T *out = (T *)p.out;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx % ((long)p.B * hw);     // pixel-major so that plane reads coalesce
+        const int q = (int)(idx / ((long)p.B * hw));
+        const int b = (int)(pix / hw);
+        const long yx = pix - (long)b * hw;
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = q * 8 + e;
+            v[e] = c < p.C ? (T)p.in[((size_t)b * p.C + c) * hw + yx] : (T)0.f;
+        }
+        T *o = out + (size_t)pix * p.Cpad + q * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[e];
+    }
+}
+
+int launch_cvt_in(const CvtInParams &p, int dtype, void *stream) {
+    const long total = (long)p.B * p.H * p.W * (p.Cpad / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_F16) hipLaunchKernelGGL(cvt_in_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(cvt_in_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// NHWC dtype -> NCHW f32 (tests / debug read-back only)
+template <typename T>
+__global__ void cvt_out_kernel(const CvtOutParams p) {
+    const long hw = (long)p.H * p.W;
+    const long total = (long)p.B * p.C * hw;
+    const T *in = (const T *)p.in;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long yx = idx % hw;
+        const long t = idx / hw;
+        const int c = (int)(t % p.C);
+        const int b = (int)(t / p.C);
+        p.out[idx] = (float)in[((size_t)b * hw + yx) * p.Cs + p.coff + c];
+    }
+}
+
+int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
+    const long total = (long)p.B * p.C * p.H * p.W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DT_F16) hipLaunchKernelGGL(cvt_out_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(cvt_out_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk

@@ -1,0 +1,127 @@
+// smk_kernels.h -- launch parameter blocks + index helpers shared by host and device code.
+// gfx950 only.  Activations are NHWC with the channel count padded to a multiple of 8;
+// weights are packed [Npad][Kpad] (K-major), K ordered (kh, kw, cin_padded), BN folded.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SMK_HD __host__ __device__ inline
+#else
+#define SMK_HD inline
+#endif
+
+namespace smk {
+
+enum { DT_F32 = 0, DT_F16 = 1 };
+enum { RES_NONE = 0, RES_PRE_RELU = 1, RES_POST_RELU = 2 };
+enum { OUT_NHWC = 0, OUT_NCHW_F32 = 1 };
+
+// K-tile = 128 bytes of K per row for both dtypes (64 f16 / 32 f32 elements)
+constexpr int KTILE_BYTES = 128;
+constexpr int NPAD_ALIGN = 128;   // weight rows padded to the largest N tile
+constexpr int KPAD_ALIGN = 64;    // elements; multiple of both K-tile sizes
+
+struct ConvParams {
+    const void *in;        // NHWC storage tensor [B][Hs][Ws][Cs] (dtype)
+    const void *wgt;       // [Npad][Kpad] (dtype)
+    const float *bias;     // [Npad] f32 (BN beta' or conv bias; zero padded)
+    const void *res;       // optional residual, NHWC [B][Ho][Wo][res_Cs] (dtype)
+    void *out;             // NHWC dtype  or  NCHW f32
+    const int *pos;        // optional per-item (y,x) pairs selecting the window origin
+    int B;
+    int Hs, Ws, Cs;        // storage dims of the input, channel stride per pixel
+    int cin_off;           // first channel of the slice that is read
+    int Ci;                // logical input channels, multiple of 8; K = kh*kw*Ci
+    int Hl, Wl;            // logical input image (window / upsampled view of the storage)
+    int org_y, org_x;      // constant origin of the logical image inside the storage
+    int pos_mul, pos_add;  // origin += pos*pos_mul + pos_add when pos != nullptr
+    int ups;               // 1: logical image = nearest-upsampled storage (sy = ly*Hs/Hl)
+    int Ho, Wo;
+    int kh, kw, stride, pad, dil;
+    int K, Kpad;
+    int N;                 // real output channels
+    int Nst;               // channels stored in NHWC mode (multiple of 4, >= N, zeros above N)
+    int M;                 // B*Ho*Wo
+    int Cos, cout_off;     // NHWC output channel stride / offset
+    int res_Cs, res_coff;
+    int relu, res_mode, out_mode;
+    // grouped launch (blockIdx.z = group): per-group element offsets
+    int groups;
+    int g_cin_off;         // added to cin_off
+    int g_wgt_off;         // rows of wgt/bias per group (multiple of NPAD_ALIGN)
+    int g_cout_off;        // added to cout_off
+};
+
+// decode a K index (start of a 16-byte vector) into tap + channel
+struct KDecode { int kh_i, kw_i, c; };
+
+SMK_HD KDecode decode_k(int kvec, int Ci, int kw) {
+    KDecode d;
+    int tap = kvec / Ci;
+    d.c = kvec - tap * Ci;
+    d.kh_i = tap / kw;
+    d.kw_i = tap - d.kh_i * kw;
+    return d;
+}
+
+// per output row (b, oy, ox): logical top-left input coordinate and window origin
+struct RowInfo { int b, ly0, lx0, oy_org, ox_org; };
+
+SMK_HD RowInfo row_info(const ConvParams &p, int m, const int *pos) {
+    RowInfo r;
+    int hw = p.Ho * p.Wo;
+    r.b = m / hw;
+    int rem = m - r.b * hw;
+    int oy = rem / p.Wo;
+    int ox = rem - oy * p.Wo;
+    r.ly0 = oy * p.stride - p.pad;
+    r.lx0 = ox * p.stride - p.pad;
+    r.oy_org = p.org_y;
+    r.ox_org = p.org_x;
+    if (pos) {
+        r.oy_org += pos[2 * r.b + 0] * p.pos_mul + p.pos_add;
+        r.ox_org += pos[2 * r.b + 1] * p.pos_mul + p.pos_add;
+    }
+    return r;
+}
+
+// element offset of input vector (row r, tap d) inside p.in, or -1 when it is zero padding
+SMK_HD long gather_offset(const ConvParams &p, const RowInfo &r, const KDecode &d, int cin_off) {
+    int ly = r.ly0 + d.kh_i * p.dil;
+    int lx = r.lx0 + d.kw_i * p.dil;
+    if ((unsigned)ly >= (unsigned)p.Hl || (unsigned)lx >= (unsigned)p.Wl) return -1;
+    int sy, sx;
+    if (p.ups) {
+        sy = (ly * p.Hs) / p.Hl;
+        sx = (lx * p.Ws) / p.Wl;
+    } else {
+        sy = ly + r.oy_org;
+        sx = lx + r.ox_org;
+    }
+    if ((unsigned)sy >= (unsigned)p.Hs || (unsigned)sx >= (unsigned)p.Ws) return -1;
+    return ((long)(r.b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off + d.c;
+}
+
+struct XcorrParams {
+    const void *x;    // [B][H][W][Cs]   (conv_search output, all branches side by side)
+    const void *k;    // [B][kh][kw][Cs] (cached conv_kernel(zf))
+    void *out;        // [B][Ho][Wo][Cs]
+    int B, H, W, kh, kw, Ho, Wo, C, Cs;
+};
+
+struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
+
+struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; };  // NCHW f32 -> NHWC dtype
+struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; };  // NHWC dtype -> NCHW f32
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------
+struct TileChoice { int bm, bn; };
+TileChoice choose_tile(const ConvParams &p, int dtype);
+int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
+int launch_conv_naive(const ConvParams &p, int dtype, void *stream);
+int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
+int launch_maxpool(const PoolParams &p, int dtype, void *stream);
+int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
+int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
+
+}  // namespace smk

@@ -1,0 +1,302 @@
+"""Drop-in ``Custom`` modules: the reference's inference surface on top of libsiammask_hip.so.
+
+Mirrors (names, argument meaning, state and error behaviour):
+  * experiments/siammask_sharp/custom.py:162-190  -> ``CustomSharp``
+  * experiments/siammask_base/custom.py:93-112    -> ``CustomBase``
+  * experiments/siamrpn_resnet/custom.py:81-93    -> ``CustomRPN``
+  * models/siammask_sharp.py:14-26, models/siamrpn.py:15-23 (attributes the tools read:
+    ``anchors``, ``anchor_num``)
+
+What the tools do with it (tools/test.py:559-569,155,201-207,257-261):
+    model = Custom(anchors=cfg['anchors']); load_pretrain(model, path); model.eval().to(device)
+    model.template(z); cls, loc, mask = model.track_mask(x); m = model.track_refine((dy, dx))
+Parameters/buffers carry the reference state-dict names and shapes (siammask_amd/spec.py), so
+an official checkpoint loads through the unchanged ``utils/load_helper.load_pretrain``.  The
+nn.Module holds the weights only; all arithmetic runs in the HIP library.  There is no CPU
+fallback: calling a method with a CPU tensor, or without the built library, raises.
+"""
+import ctypes
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, spec
+
+
+class _Node(nn.Module):
+    """Parameter container mirroring one node of the reference module tree."""
+
+    def __init__(self, tree):
+        super(_Node, self).__init__()
+        for name, sub in tree.items():
+            if isinstance(sub, OrderedDict):
+                self.add_module(name, _Node(sub))
+            else:
+                shape, kind = sub
+                if kind in ("conv_w", "deconv_w", "bias", "bn_w", "bn_b"):
+                    init = torch.ones(shape) if kind == "bn_w" else torch.zeros(shape)
+                    self.register_parameter(name, nn.Parameter(init, requires_grad=False))
+                elif kind == "bn_mean":
+                    self.register_buffer(name, torch.zeros(shape))
+                elif kind == "bn_var":
+                    self.register_buffer(name, torch.ones(shape))
+                elif kind == "bn_nbt":
+                    self.register_buffer(name, torch.tensor(0, dtype=torch.long))
+                else:
+                    raise KeyError(kind)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("siammask_amd parameter containers are not callable; use "
+                           "Custom.template/track/track_mask/track_refine")
+
+
+class Custom(nn.Module):
+    """Base of the three variants.  Constructor signature follows the reference:
+    ``Custom(pretrain=False, anchors=<dict>)``; extra keyword-only knobs:
+
+    dtype      'f32' (default; the reference's precision) or 'f16' (fp16 storage, fp32
+               accumulate).  Env override: SIAMMASK_AMD_DTYPE.
+    max_batch  streams tracked in lock-step by this instance (default 1, grows on demand).
+    graph      replay captured hipGraphs (default: env SIAMMASK_AMD_GRAPH, else on).
+    lazy_mask  sharp only: skip the 3969-channel mask head in track_mask (its result is never
+               read when track_refine is used, tools/test.py:256-258) and return None for it.
+    """
+    variant = None
+
+    def __init__(self, pretrain=False, anchors=None, o_sz=127, g_sz=127, dtype=None, max_batch=1,
+                 graph=None, lazy_mask=False, **kwargs):
+        super(Custom, self).__init__()
+        if anchors is None:
+            raise ValueError("Custom(anchors=...) is required (tools/test.py:560)")
+        if pretrain:
+            raise NotImplementedError("pretrain=True loads 'resnet.model' for training; "
+                                      "the MI355X path is inference only")
+        self.anchors = anchors
+        self.anchor_num = len(anchors["ratios"]) * len(anchors["scales"])
+        if self.anchor_num != spec.ANCHOR_NUM:
+            raise ValueError("kernels are specialised for 5 anchors (config_*.json); got %d" % self.anchor_num)
+        self.o_sz, self.g_sz = o_sz, g_sz
+        self.all_anchors = None
+        tree = spec.module_tree(self.variant)
+        for name, sub in tree.items():
+            self.add_module(name, _Node(sub))
+        dtype = dtype or os.environ.get("SIAMMASK_AMD_DTYPE", "f32")
+        if dtype not in _lib.DTYPE:
+            raise ValueError("dtype %r" % (dtype,))
+        self._dtype = dtype
+        if graph is None:
+            graph = os.environ.get("SIAMMASK_AMD_GRAPH", "1") != "0"
+        self._graph = bool(graph)
+        self._lazy_mask = bool(lazy_mask)
+        self._max_batch = int(max_batch)
+        self._ctx = None
+        self._ctx_device = None
+        self._weights_dirty = True
+        self._io = {}
+        self._tracked = 0
+        self.zf = None          # reference attribute (custom.py:174); opaque handle here
+
+    # -- weights --------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        self._weights_dirty = True
+        return super(Custom, self).load_state_dict(state_dict, strict=strict)
+
+    def _apply(self, fn, *a, **k):
+        self._weights_dirty = True
+        return super(Custom, self)._apply(fn, *a, **k)
+
+    def mark_weights_dirty(self):
+        self._weights_dirty = True
+
+    # -- context ----------------------------------------------------------------------------
+    def _ensure(self, x, batch):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise RuntimeError("siammask_amd runs on the MI355X only: expected a CUDA(HIP) tensor, got %s"
+                               % (x.device if isinstance(x, torch.Tensor) else type(x)))
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        L = _lib.lib()
+        if self._ctx is not None and (dev != self._ctx_device or batch > self._max_batch):
+            self._destroy()
+        if self._ctx is None:
+            self._max_batch = max(self._max_batch, batch)
+            ctx = ctypes.c_void_p()
+            _lib.check(L.smk_create(ctypes.byref(ctx), dev, _lib.DTYPE[self._dtype],
+                                    _lib.VARIANT[self.variant], self._max_batch))
+            self._ctx, self._ctx_device = ctx, dev
+            _lib.check(L.smk_set_graph_mode(ctx, 1 if self._graph else 0))
+            self._weights_dirty = True
+            self._io = {}
+        if self._weights_dirty:
+            for name, t in self.state_dict().items():
+                if name.endswith("num_batches_tracked"):
+                    continue
+                a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+                shape = (ctypes.c_int64 * max(1, a.ndim))(*a.shape)
+                _lib.check(L.smk_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                            shape, a.ndim))
+            _lib.check(L.smk_finalize_weights(self._ctx))
+            self._weights_dirty = False
+            self._tracked = 0
+            self.zf = None
+
+    def _destroy(self):
+        if self._ctx is not None:
+            torch.cuda.synchronize()
+            _lib.lib().smk_destroy(self._ctx)
+        self._ctx = None
+        self._io = {}
+        self.zf = None
+        self._tracked = 0
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _buf(self, key, shape, device):
+        t = self._io.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
+            t = torch.empty(shape, dtype=torch.float32, device=device)
+            self._io[key] = t
+        return t
+
+    def _stage_in(self, key, x, size):
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != size or x.shape[3] != size:
+            raise ValueError("expected a [B,3,%d,%d] tensor, got %s" % (size, size, tuple(x.shape)))
+        if self._graph:
+            # stable pointer => the captured graph is replayed
+            buf = self._buf(key, tuple(x.shape), x.device)
+            buf.copy_(x)
+            return buf
+        return x.to(torch.float32).contiguous()
+
+    def _out(self, key, shape, device):
+        if self._graph:
+            return self._buf(key, shape, device)
+        return torch.empty(shape, dtype=torch.float32, device=device)
+
+    # -- the reference surface ------------------------------------------------------------------
+    def template(self, template):
+        """custom.py:173-174 -- caches the template features (and conv_kernel(zf)) on device."""
+        B = template.shape[0]
+        self._ensure(template, B)
+        with torch.cuda.device(self._ctx_device):
+            z = self._stage_in("z", template, spec.TEMPLATE_SIZE)
+            _lib.check(_lib.lib().smk_template(self._ctx, z.data_ptr(), B, _lib.current_stream_ptr()))
+        self.zf = ("device-resident", B)
+        self._tracked = 0
+
+    def _track(self, search, flags, want_mask):
+        if self.zf is None:
+            raise RuntimeError("template() must be called before track()/track_mask()")
+        B = search.shape[0]
+        self._ensure(search, B)
+        if self.zf is None:
+            raise RuntimeError("weights changed since template(); call template() again")
+        dev = search.device
+        with torch.cuda.device(self._ctx_device):
+            x = self._stage_in("x", search, spec.SEARCH_SIZE)
+            cls = self._out("cls", (B, 2 * self.anchor_num, spec.SCORE_SIZE, spec.SCORE_SIZE), dev)
+            loc = self._out("loc", (B, 4 * self.anchor_num, spec.SCORE_SIZE, spec.SCORE_SIZE), dev)
+            mask = None
+            if want_mask:
+                mask = self._out("mask", (B, spec.MASK_OUT ** 2, spec.SCORE_SIZE, spec.SCORE_SIZE), dev)
+            _lib.check(_lib.lib().smk_track(
+                self._ctx, x.data_ptr(), B, flags, cls.data_ptr(), loc.data_ptr(),
+                mask.data_ptr() if mask is not None else None, _lib.current_stream_ptr()))
+        if self._graph:
+            cls, loc = cls.clone(), loc.clone()      # small; mask stays a view of the I/O buffer
+        return cls, loc, mask
+
+    def track(self, search):
+        """custom.py:176-179 -> (rpn_pred_cls [B,10,25,25], rpn_pred_loc [B,20,25,25])."""
+        cls, loc, _ = self._track(search, _lib.TRACK_BOX, False)
+        self._tracked = 0
+        return cls, loc
+
+    def __repr__(self):
+        return "%s(variant=%s, dtype=%s, graph=%s)" % (type(self).__name__, self.variant, self._dtype, self._graph)
+
+
+class CustomRPN(Custom):
+    """experiments/siamrpn_resnet/custom.py:81-93 (box only)."""
+    variant = "rpn"
+
+
+class CustomBase(Custom):
+    """experiments/siammask_base/custom.py:93-112 (3-branch, 63x63 mask head, no Refine)."""
+    variant = "base"
+
+    def track_mask(self, search):
+        """-> (cls, loc, pred_mask [B,3969,25,25])."""
+        out = self._track(search, _lib.TRACK_MASK, True)
+        self._tracked = search.shape[0]
+        return out
+
+
+class CustomSharp(CustomBase):
+    """experiments/siammask_sharp/custom.py:162-190 (mask branch + Refine)."""
+    variant = "sharp"
+
+    def track_mask(self, search):
+        if self._lazy_mask:
+            cls, loc, _ = self._track(search, _lib.TRACK_MASK | _lib.TRACK_NO_MASK_HEAD, False)
+            self._tracked = search.shape[0]
+            return cls, loc, None
+        return super(CustomSharp, self).track_mask(search)
+
+    def track_refine(self, pos):
+        """custom.py:188-190.  ``pos`` = (y, x) for the whole batch (reference semantics), or a
+        [B,2] int array / tensor of per-stream positions (extension for batched streams).
+        -> [B, 127*127] mask logits."""
+        if not self._tracked:
+            raise RuntimeError("track_refine() requires a preceding track_mask()")
+        B = self._tracked
+        L = _lib.lib()
+        dev = torch.device("cuda", self._ctx_device)
+        with torch.cuda.device(self._ctx_device):
+            out = self._out("refine", (B, spec.REFINE_OUT ** 2), dev)
+            if isinstance(pos, torch.Tensor) and pos.is_cuda:
+                p = pos.to(torch.int32).contiguous().view(-1)
+                if p.numel() != 2 * B:
+                    raise ValueError("pos tensor must have shape [B,2]")
+                _lib.check(L.smk_refine(self._ctx, p.data_ptr(), 1, B, out.data_ptr(), _lib.current_stream_ptr()))
+            else:
+                a = np.asarray(pos.cpu() if isinstance(pos, torch.Tensor) else pos, dtype=np.int32)
+                if a.ndim == 1:
+                    a = np.tile(a.reshape(1, 2), (B, 1))
+                if a.shape != (B, 2):
+                    raise ValueError("pos must be (y, x) or [B,2]")
+                a = np.ascontiguousarray(a)
+                _lib.check(L.smk_refine(self._ctx, a.ctypes.data_as(ctypes.c_void_p), 0, B, out.data_ptr(),
+                                        _lib.current_stream_ptr()))
+        return out
+
+    def debug_tensor(self, name):
+        """Read an internal activation back as f32 NCHW (parity tests)."""
+        L = _lib.lib()
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.smk_debug_read(self._ctx, name.encode(), None, ctypes.byref(c), ctypes.byref(h),
+                                    ctypes.byref(w), None))
+        B = self._tracked or (self.zf[1] if self.zf else 1)
+        with torch.cuda.device(self._ctx_device):
+            t = torch.empty((B, c.value, h.value, w.value), dtype=torch.float32,
+                            device=torch.device("cuda", self._ctx_device))
+            _lib.check(L.smk_debug_read(self._ctx, name.encode(), t.data_ptr(), ctypes.byref(c), ctypes.byref(h),
+                                        ctypes.byref(w), _lib.current_stream_ptr()))
+        return t
+
+
+CustomBase.debug_tensor = CustomSharp.debug_tensor
+CustomRPN.debug_tensor = CustomSharp.debug_tensor
+
+VARIANT_CLASS = {"rpn": CustomRPN, "base": CustomBase, "sharp": CustomSharp}
+
+
+def build(variant="sharp", anchors=None, **kw):
+    anchors = anchors or {"stride": 8, "ratios": [0.33, 0.5, 1, 2, 3], "scales": [8], "round_dight": 0}
+    return VARIANT_CLASS[variant](anchors=anchors, **kw)

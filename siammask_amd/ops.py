@@ -1,0 +1,82 @@
+"""Per-op entry points of libsiammask_hip.so on torch CUDA(HIP) tensors (unit parity tests).
+
+conv2d    -> the implicit-GEMM MFMA kernel every convolution of the path uses
+dw_xcorr  -> models/rpn.py:32-38 conv2d_dw_group
+maxpool   -> nn.MaxPool2d(3, 2, 1) (experiments/siammask_sharp/resnet.py:158)
+All take / return float32 NCHW tensors; ``dtype`` selects the device arithmetic type."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3}
+TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4}
+
+
+def _chk_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("siammask_amd.ops run on the MI355X only (got a CPU tensor)")
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=1, dtype="f32",
+           algo="mfma", tile=None, win=None, ups=None, pos=None, pos_mul=0, pos_add=0, org=(0, 0),
+           cin_off=0, cin_len=0):
+    _chk_cuda(x, res)
+    x = x.contiguous().float()
+    B, Cin, H, W = x.shape
+    w = np.ascontiguousarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32)
+    bb = None if b is None else np.ascontiguousarray(
+        b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b, dtype=np.float32)
+    g = _lib.ConvGeom()
+    g.B, g.Cin, g.H, g.W = B, Cin, H, W
+    g.Cout, g.k, g.stride, g.pad, g.dil = w.shape[0], w.shape[2], stride, pad, dil
+    g.relu = int(bool(relu))
+    g.res_mode = res_mode if res is not None else 0
+    g.cin_off, g.cin_len = cin_off, cin_len
+    g.org_y, g.org_x = org
+    g.pos_mul, g.pos_add = pos_mul, pos_add
+    Hl, Wl = H, W
+    if win is not None:
+        g.win, g.Hl, g.Wl = 1, win[0], win[1]
+        Hl, Wl = win
+    if ups is not None:
+        g.ups, g.Hl, g.Wl = 1, ups[0], ups[1]
+        Hl, Wl = ups
+    Ho = (Hl + 2 * pad - dil * (g.k - 1) - 1) // stride + 1
+    Wo = (Wl + 2 * pad - dil * (g.k - 1) - 1) // stride + 1
+    y = torch.empty((B, g.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    p = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+    r = None if res is None else res.contiguous().float()
+    code = ALGO[algo] | (TILE[tile] << 8)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().smk_op_conv2d_ex(
+            _lib.DTYPE[dtype], code, ctypes.byref(g), x.data_ptr(), vp(w), vp(bb),
+            r.data_ptr() if r is not None else None, vp(p), y.data_ptr(), _lib.current_stream_ptr()))
+    return y
+
+
+def dw_xcorr(x, k, dtype="f32"):
+    _chk_cuda(x, k)
+    x, k = x.contiguous().float(), k.contiguous().float()
+    B, C, H, W = x.shape
+    kh, kw = k.shape[2], k.shape[3]
+    y = torch.empty((B, C, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().smk_op_dw_xcorr(_lib.DTYPE[dtype], x.data_ptr(), k.data_ptr(), B, C, H, W, kh, kw,
+                                              y.data_ptr(), _lib.current_stream_ptr()))
+    return y
+
+
+def maxpool3x3s2(x, dtype="f32"):
+    _chk_cuda(x)
+    x = x.contiguous().float()
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().smk_op_maxpool3x3s2(_lib.DTYPE[dtype], x.data_ptr(), B, C, H, W, y.data_ptr(),
+                                                  _lib.current_stream_ptr()))
+    return y

@@ -1,0 +1,152 @@
+"""End-to-end GPU parity of the drop-in Custom (all arithmetic in libsiammask_hip.so, called
+through the C ABI) against (a) the golden vectors produced by the reference itself
+(tests/golden, oracle/make_golden.py) and (b) the CPU oracle for every intermediate tensor.
+
+Tolerances, rel. to max|ref| per tensor:
+  fp32 path: 1e-4 on synthetic_damped, 5e-4 on synthetic_stress; argmax box index bit-exact.
+  fp16 path: 3e-2 on cls/loc/mask, 1e-2 on the refine logits (loose gate vs the fp32 truth;
+             the synthetic net amplifies perturbations ~27x); argmax reported.
+Per-tensor errors of every run are written to gpurun_out/e2e_*.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.np_oracle import Oracle, decode_best
+from siammask_amd import synth
+from helpers import CASES, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "gpurun_out")
+
+
+def _model(variant, fixture, dtype, graph, **kw):
+    from siammask_amd.custom import build
+    m = build(variant, dtype=dtype, graph=graph, **kw)
+    m.load_state_dict(synth.torch_state_dict(variant, fixture))
+    return m.eval().cuda()
+
+
+def _cat(o, key, names):
+    return np.concatenate([o.dbg["%s_%s" % (key, n)] for n in names], axis=1)
+
+
+def _run_case(case, dtype, graph):
+    g = load_golden(case)
+    variant, fixture = str(g["variant"]), str(g["fixture"])
+    z = torch.from_numpy(g["z_u8"].astype(np.float32)).cuda()
+    x = torch.from_numpy(g["x_u8"].astype(np.float32)).cuda()
+    B = x.shape[0]
+    m = _model(variant, fixture, dtype, graph)
+    o = Oracle(synth.state_dict(variant, fixture), variant)
+    o.template(g["z_u8"].astype(np.float64))
+    errs = {}
+    m.template(z)
+    errs["zf"] = rel_err(m.debug_tensor("zf").cpu().numpy(), o.zf)
+    names = ["cls", "loc"] + (["mask"] if variant != "rpn" else [])
+    if variant == "rpn":
+        cls, loc = m.track(x)
+        ocls, oloc = o.track(g["x_u8"].astype(np.float64))
+        mask = None
+    else:
+        cls, loc, mask = m.track_mask(x)
+        ocls, oloc, omask = o.track_mask(g["x_u8"].astype(np.float64))
+    errs["zk"] = rel_err(m.debug_tensor("zk").cpu().numpy(), _cat(o, "zk", names))
+    if variant != "rpn":
+        for i, n in enumerate(("p0", "p1", "p2")):
+            errs[n] = rel_err(m.debug_tensor(n).cpu().numpy(), o.feature[i])
+    errs["search"] = rel_err(m.debug_tensor("search").cpu().numpy(), o.search if variant != "rpn" else
+                             o.resdown(g["x_u8"].astype(np.float64))[1])
+    for key in ("xs", "corr", "head0"):
+        errs[key] = rel_err(m.debug_tensor(key).cpu().numpy(), _cat(o, key, names))
+    cls_np, loc_np = cls.cpu().numpy(), loc.cpu().numpy()
+    errs["cls"] = rel_err(cls_np, g["cls"])
+    errs["loc"] = rel_err(loc_np, g["loc"])
+    errs["cls_vs_oracle"] = rel_err(cls_np, ocls)
+    best_ok = []
+    for b in range(B):
+        bid, dy, dx, _ = decode_best(cls_np[b], loc_np[b])
+        best_ok.append(bid == int(g["best_id"][b]))
+    if mask is not None:
+        mk = mask.cpu().numpy()
+        errs["mask"] = rel_err(mk, omask)
+        errs["mask_col"] = max(rel_err(mk[b, :, g["best_yx"][b][0], g["best_yx"][b][1]], g["mask_col"][b])
+                               for b in range(B))
+    if variant == "sharp":
+        r = m.track_refine(g["best_yx"]).cpu().numpy()
+        errs["refine"] = rel_err(r, g["refine"])
+        iou = []
+        for b in range(B):
+            a_, b_ = r[b] > 0, g["refine"][b] > 0
+            iou.append(float((a_ & b_).sum() / max(1, (a_ | b_).sum())))
+        errs["refine_iou_min"] = min(iou)
+        sp = tuple(int(v) for v in g["shared_pos"])
+        errs["refine_shared"] = rel_err(m.track_refine(sp).cpu().numpy(), g["refine_shared"])
+    report = {"case": case, "dtype": dtype, "graph": graph, "errors": errs, "argmax_equal": best_ok,
+              "top2_gap": [float(v) for v in g["top2_gap"]]}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "e2e_%s_%s_g%d.json" % (case, dtype, int(graph))), "w") as f:
+        json.dump(report, f, indent=1)
+    return report, fixture
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("case", CASES)
+def test_fp32_matches_reference(case, graph):
+    rep, fixture = _run_case(case, "f32", graph)
+    tol = 5e-4 if fixture == "synthetic_stress" else 1e-4
+    bad = {k: v for k, v in rep["errors"].items() if k != "refine_iou_min" and not v <= tol}
+    assert not bad, "fp32 %s: %s (all %s)" % (case, bad, rep["errors"])
+    assert all(rep["argmax_equal"]), "argmax box index differs: %s" % rep
+    if "refine_iou_min" in rep["errors"]:
+        assert rep["errors"]["refine_iou_min"] >= 0.999
+
+
+@pytest.mark.parametrize("case", ["sharp_damped_b2", "base_damped_b1", "rpn_damped_b1"])
+def test_fp16_loose_gate(case):
+    rep, _ = _run_case(case, "f16", True)
+    e = rep["errors"]
+    for k in ("cls", "loc", "mask"):
+        if k in e:
+            assert e[k] <= 3e-2, "fp16 %s %s: %s" % (case, k, e)
+    if "refine" in e:
+        assert e["refine"] <= 1e-2 and e["refine_iou_min"] >= 0.995, e
+
+
+def test_batch_invariance_and_order_errors():
+    """B=2 equals two B=1 runs; call-order and batch-mismatch errors surface as exceptions."""
+    g = load_golden("sharp_damped_b2")
+    z = torch.from_numpy(g["z_u8"].astype(np.float32)).cuda()
+    x = torch.from_numpy(g["x_u8"].astype(np.float32)).cuda()
+    m = _model("sharp", "synthetic_damped", "f32", False, max_batch=2)
+    with pytest.raises(RuntimeError):
+        m.track_mask(x)                      # before template
+    m.template(z)
+    c2, l2, k2 = [t.clone() for t in m.track_mask(x)]
+    r2 = m.track_refine(g["best_yx"]).clone()
+    with pytest.raises(RuntimeError):
+        m.track(x[:1])                       # batch != template batch (models/rpn.py:33)
+    for b in range(2):
+        m.template(z[b:b + 1])
+        c1, l1, k1 = m.track_mask(x[b:b + 1])
+        r1 = m.track_refine(tuple(int(v) for v in g["best_yx"][b]))
+        for a_, b_ in ((c1, c2[b:b + 1]), (l1, l2[b:b + 1]), (k1, k2[b:b + 1]), (r1, r2[b:b + 1])):
+            assert (a_ - b_).abs().max().item() <= 1e-5 * b_.abs().max().item()
+    cb, lb = m.track(x[1:2])                 # box-only path equals the mask path's cls/loc
+    assert (cb - c2[1:2]).abs().max().item() <= 1e-5 * c2.abs().max().item()
+    assert (lb - l2[1:2]).abs().max().item() <= 1e-5 * l2.abs().max().item()
+
+
+def test_lazy_mask_head_matches():
+    g = load_golden("sharp_damped_b2")
+    z = torch.from_numpy(g["z_u8"].astype(np.float32)).cuda()
+    x = torch.from_numpy(g["x_u8"].astype(np.float32)).cuda()
+    m = _model("sharp", "synthetic_damped", "f32", True, lazy_mask=True)
+    m.template(z)
+    cls, loc, mask = m.track_mask(x)
+    assert mask is None
+    assert rel_err(cls.cpu().numpy(), g["cls"]) <= 1e-4
+    assert rel_err(m.track_refine(g["best_yx"]).cpu().numpy(), g["refine"]) <= 1e-4

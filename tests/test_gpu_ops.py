@@ -1,0 +1,167 @@
+"""GPU parity of the individual HIP kernels against the CPU oracle (oracle/np_oracle.py),
+called through the C ABI (smk_op_*).  Tolerances (rel. to max|ref|):
+  fp32 path : 2e-5   (exact-fp32 MFMA fma chains, K <= 4608; oracle in float64)
+  fp16 path : 2e-3   (inputs/weights rounded to fp16 first, fp32 accumulate, fp16 store)
+Every distinct convolution class of SURVEY.md Appendix D is covered at reduced channel
+counts plus the real heavy shapes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-5, "f16": 2e-3}
+
+
+def _ops():
+    from siammask_amd import ops
+    return ops
+
+
+def _q(a, dtype):
+    """round to the device storage type (the kernels see fp16-rounded inputs in f16 mode)"""
+    return a.astype(np.float16).astype(np.float64) if dtype == "f16" else a.astype(np.float64)
+
+
+def _rand(rng, *shape):
+    return rng.uniform(-1, 1, size=shape).astype(np.float32)
+
+
+CONV_CLASSES = [
+    # cin, cout, k, stride, pad, dil, hw, B
+    (3, 64, 7, 2, 0, 1, 63, 2),       # stem (Cin=3 -> 8)
+    (64, 64, 1, 1, 0, 1, 31, 2),      # l1 1x1
+    (64, 64, 3, 1, 1, 1, 31, 2),      # l1 3x3 p1
+    (128, 128, 3, 2, 0, 1, 31, 1),    # l2.0 3x3 s2 p0
+    (256, 256, 3, 1, 2, 2, 15, 1),    # l3 3x3 d2 p2
+    (256, 256, 3, 1, 0, 1, 15, 1),    # conv_search 3x3 p0
+    (512, 96, 3, 1, 1, 1, 9, 3),      # big K, odd N
+    (256, 10, 1, 1, 0, 1, 25, 2),     # cls head (N=10)
+    (32, 16, 3, 1, 1, 1, 15, 2),      # refine small
+    (4, 1, 3, 1, 1, 1, 21, 2),        # refine tail Cin=4 Cout=1
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cfg", CONV_CLASSES)
+def test_conv_classes(cfg, dtype):
+    ops = _ops()
+    cin, cout, k, stride, pad, dil, hw, B = cfg
+    rng = np.random.default_rng(hash(cfg) & 0xffff)
+    x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k), _rand(rng, cout)
+    ref = O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64), stride, pad, dil)
+    xd = torch.from_numpy(x).cuda()
+    errs = {}
+    for algo in ("naive", "mfma", "mfma_nchw", "naive_nchw"):
+        y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo=algo).cpu().numpy()
+        errs[algo] = rel_err(y, ref)
+    for tile in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo="mfma", tile=tile).cpu().numpy()
+        errs["mfma%s" % (tile,)] = rel_err(y, ref)
+        y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo="mfma_nchw", tile=tile).cpu().numpy()
+        errs["nchw%s" % (tile,)] = rel_err(y, ref)
+    bad = {a: e for a, e in errs.items() if not e <= TOL[dtype]}
+    assert not bad, "conv %s %s: %s (all: %s)" % (cfg, dtype, bad, errs)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv_epilogues(dtype):
+    """bias + residual (before / after ReLU) + ReLU, as used by Bottleneck (resnet.py:99-101)
+    and Refine's h(out)+v(p) sums (custom.py:150-152)."""
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    x, w, b = _rand(rng, 2, 64, 17, 17), _rand(rng, 96, 64, 1, 1) / 8, _rand(rng, 96)
+    res = _rand(rng, 2, 96, 17, 17)
+    base = O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64))
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
+    for algo in ("naive", "mfma"):
+        y = ops.conv2d(xd, w, b, relu=True, dtype=dtype, algo=algo).cpu().numpy()
+        assert rel_err(y, np.maximum(base, 0)) <= TOL[dtype]
+        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=1, dtype=dtype, algo=algo).cpu().numpy()
+        assert rel_err(y, np.maximum(base + _q(res, dtype), 0)) <= TOL[dtype]
+        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=2, dtype=dtype, algo=algo).cpu().numpy()
+        assert rel_err(y, np.maximum(base, 0) + _q(res, dtype)) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv_window_upsample_slice(dtype):
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    f = _rand(rng, 3, 64, 31, 31)
+    w = _rand(rng, 32, 64, 3, 3) / 24
+    pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
+    fp = np.pad(_q(f, dtype), ((0, 0), (0, 0), (4, 4), (4, 4)))
+    ref = np.concatenate([O.conv2d(fp[b:b + 1, :, y:y + 15, x:x + 15], _q(w, dtype), None, 1, 1, 1)
+                          for b, (y, x) in enumerate(pos)])
+    fd = torch.from_numpy(f).cuda()
+    for algo in ("naive", "mfma"):
+        y = ops.conv2d(fd, w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4, dtype=dtype, algo=algo)
+        assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype], algo
+    x = _rand(rng, 2, 32, 15, 15)
+    w2 = _rand(rng, 16, 32, 3, 3) / 17
+    ref = O.conv2d(O.upsample_nearest(_q(x, dtype), 31), _q(w2, dtype), None, 1, 1, 1)
+    for algo in ("naive", "mfma", "mfma_nchw"):
+        y = ops.conv2d(torch.from_numpy(x).cuda(), w2, pad=1, ups=(31, 31), dtype=dtype, algo=algo)
+        assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype], algo
+    x = _rand(rng, 2, 96, 9, 9)
+    w3 = _rand(rng, 24, 32, 1, 1) / 6
+    ref = O.conv2d(_q(x[:, 32:64], dtype), _q(w3, dtype))
+    y = ops.conv2d(torch.from_numpy(x).cuda(), w3, cin_off=32, cin_len=32, dtype=dtype)
+    assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype]
+    # template centre crop folded into the adjust conv (custom.py:21-24)
+    x = _rand(rng, 2, 64, 15, 15)
+    w4 = _rand(rng, 32, 64, 1, 1) / 8
+    ref = O.conv2d(_q(x, dtype), _q(w4, dtype))[:, :, 4:-4, 4:-4]
+    y = ops.conv2d(torch.from_numpy(x).cuda(), w4, win=(7, 7), org=(4, 4), dtype=dtype)
+    assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_heavy_real_shapes(dtype):
+    """the two heaviest GEMM classes at their real size, B=1."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    for cin, cout, k, pad, dil in ((512, 1024, 3, 1, 1), (1024, 256, 1, 0, 1)):
+        x = _rand(rng, 1, cin, 31, 31)
+        w = _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k)
+        ref = O.conv2d(_q(x, dtype), _q(w, dtype), None, 1, pad, dil)
+        y = ops.conv2d(torch.from_numpy(x).cuda(), w, pad=pad, dil=dil, dtype=dtype).cpu().numpy()
+        assert rel_err(y, ref) <= TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("shape", [(2, 256, 29, 29, 5, 5), (1, 768, 29, 29, 5, 5), (3, 64, 12, 9, 3, 2)])
+def test_dw_xcorr(shape, dtype):
+    """models/rpn.py:32-38 conv2d_dw_group; includes a ragged (non-square, small tap) case."""
+    ops = _ops()
+    B, C, H, W, kh, kw = shape
+    rng = np.random.default_rng(17)
+    x, k = _rand(rng, B, C, H, W), _rand(rng, B, C, kh, kw)
+    ref = O.conv2d_dw_group(_q(x, dtype), _q(k, dtype))
+    y = ops.dw_xcorr(torch.from_numpy(x).cuda(), torch.from_numpy(k).cuda(), dtype=dtype).cpu().numpy()
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) <= TOL[dtype]
+
+
+def test_dw_xcorr_linearity_full_batch():
+    """size-independent property at the BASELINE batch (64): xcorr is bilinear."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x1, x2 = torch.randn(64, 768, 29, 29, generator=g).cuda(), torch.randn(64, 768, 29, 29, generator=g).cuda()
+    k = torch.randn(64, 768, 5, 5, generator=g).cuda()
+    a = ops.dw_xcorr(x1, k) + 2.0 * ops.dw_xcorr(x2, k)
+    b = ops.dw_xcorr(x1 + 2.0 * x2, k)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_maxpool(dtype):
+    ops = _ops()
+    rng = np.random.default_rng(19)
+    for hw in (125, 61, 8):
+        x = np.maximum(_rand(rng, 2, 64, hw, hw), 0)   # post-ReLU input as on the path
+        ref = O.maxpool_3x3_s2_p1(_q(x, dtype))
+        y = ops.maxpool3x3s2(torch.from_numpy(x).cuda(), dtype=dtype).cpu().numpy()
+        assert y.shape == ref.shape and rel_err(y, ref) == 0.0   # max is exact

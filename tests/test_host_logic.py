@@ -1,0 +1,151 @@
+"""CPU tests of the host logic of libsiammask_hip.so (no GPU needed):
+the C-ABI library loads and exports every declared symbol, and the weight packing order +
+the kernels' own row/tap decode + gather-offset functions (shared host/device code in
+siammask_amd/csrc/smk_kernels.h), walked on the host by smk_host_conv2d_ex, reproduce the
+oracle's conv2d for every geometry class on the path, including the Refine windows
+(custom.py:133-135), the template centre crop (custom.py:21-24) and nearest upsampling
+(custom.py:150-152)."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from siammask_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "siammask_hip.h")).read()
+    declared = set(re.findall(r"\b(smk_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("smk_ctx")
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.smk_version() >> 16 == 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = _lib.lib()
+    ctx = ctypes.c_void_p()
+    rc = L.smk_create(ctypes.byref(ctx), 0, 0, 2, 1)
+    assert rc == -5 and b"no HIP device" in L.smk_last_error()
+    with pytest.raises(_lib.SmkError):
+        _lib.check(rc)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def host_conv(x, w, b=None, res=None, pos=None, **kw):
+    g = _lib.ConvGeom()
+    B, Cin, H, W = x.shape
+    g.B, g.Cin, g.H, g.W = B, Cin, H, W
+    g.Cout, g.k = w.shape[0], w.shape[2]
+    g.stride, g.pad, g.dil = kw.get("stride", 1), kw.get("pad", 0), kw.get("dil", 1)
+    for f in ("relu", "res_mode", "win", "ups", "Hl", "Wl", "org_y", "org_x", "pos_mul", "pos_add",
+              "cin_off", "cin_len"):
+        setattr(g, f, kw.get(f, 0))
+    Hl = g.Hl if (g.win or g.ups) else H
+    Wl = g.Wl if (g.win or g.ups) else W
+    Ho = (Hl + 2 * g.pad - g.dil * (g.k - 1) - 1) // g.stride + 1
+    Wo = (Wl + 2 * g.pad - g.dil * (g.k - 1) - 1) // g.stride + 1
+    y = np.zeros((B, g.Cout, Ho, Wo), dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    res = None if res is None else np.ascontiguousarray(res, dtype=np.float32)
+    pos = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+    _lib.check(_lib.lib().smk_host_conv2d_ex(ctypes.byref(g), _fp(x), _fp(w), _fp(b), _fp(res), _fp(pos), _fp(y)))
+    return y
+
+
+RNG = np.random.default_rng(7)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [
+    (3, 16, 7, 2, 0, 1, 31),      # stem class: 7x7 s2 p0, Cin=3 padded to 8
+    (16, 24, 1, 1, 0, 1, 9),      # 1x1
+    (16, 16, 3, 1, 1, 1, 9),      # 3x3 s1 p1
+    (16, 8, 3, 2, 0, 1, 13),      # 3x3 s2 p0 (layer2.0)
+    (8, 8, 3, 1, 2, 2, 11),       # 3x3 d2 p2 (layer3.1-5)
+    (8, 12, 3, 1, 0, 1, 9),       # 3x3 p0 (conv_search / conv_kernel)
+    (4, 1, 3, 1, 1, 1, 10),       # Refine tail: Cin=4 (padded to 8), Cout=1
+])
+def test_host_walk_matches_oracle_conv(cin, cout, k, stride, pad, dil, hw):
+    x = RNG.normal(size=(2, cin, hw, hw)).astype(np.float32)
+    w = RNG.normal(size=(cout, cin, k, k)).astype(np.float32)
+    b = RNG.normal(size=(cout,)).astype(np.float32)
+    ref = O.conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), stride, pad, dil)
+    got = host_conv(x, w, b, stride=stride, pad=pad, dil=dil)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-4
+    res = RNG.normal(size=ref.shape).astype(np.float32)
+    got = host_conv(x, w, b, res=res, stride=stride, pad=pad, dil=dil, relu=1, res_mode=1)
+    assert np.abs(got - np.maximum(ref + res, 0)).max() < 1e-4
+    got = host_conv(x, w, b, res=res, stride=stride, pad=pad, dil=dil, relu=1, res_mode=2)
+    assert np.abs(got - (np.maximum(ref, 0) + res)).max() < 1e-4
+
+
+def test_refine_window_and_positions():
+    """F.pad(f, n)[..., m*y:m*y+S, m*x:m*x+S] then conv3x3 p1 (custom.py:133-135)."""
+    w = RNG.normal(size=(16, 8, 3, 3)).astype(np.float32)
+    pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
+    for mul, padn, S, F in ((1, 4, 15, 31), (2, 8, 31, 63)):
+        f = RNG.normal(size=(3, 8, F, F)).astype(np.float32)
+        fp = np.pad(f, ((0, 0), (0, 0), (padn, padn), (padn, padn))).astype(np.float64)
+        ref = np.concatenate([
+            O.conv2d(fp[b:b + 1, :, mul * y:mul * y + S, mul * x:mul * x + S], w.astype(np.float64), None, 1, 1, 1)
+            for b, (y, x) in enumerate(pos)])
+        got = host_conv(f, w, pos=pos, pad=1, win=1, Hl=S, Wl=S, pos_mul=mul, pos_add=-padn)
+        assert np.abs(got - ref).max() < 1e-4
+
+
+def test_template_centre_crop_and_gather():
+    """ResDownS crop x[:, :, 4:-4, 4:-4] folded into the 1x1 conv (custom.py:21-24) and the
+    corr_feature[:, :, y, x] gather of Refine (custom.py:145) as a 1x1 window."""
+    x = RNG.normal(size=(2, 16, 15, 15)).astype(np.float32)
+    w = RNG.normal(size=(8, 16, 1, 1)).astype(np.float32)
+    ref = O.conv2d(x.astype(np.float64), w.astype(np.float64))[:, :, 4:-4, 4:-4]
+    got = host_conv(x, w, win=1, Hl=7, Wl=7, org_y=4, org_x=4)
+    assert np.abs(got - ref).max() < 1e-4
+    pos = np.array([[3, 9], [14, 0]], dtype=np.int32)
+    ref = np.stack([O.conv2d(x[b:b + 1, :, y:y + 1, xx:xx + 1].astype(np.float64), w.astype(np.float64))[0]
+                    for b, (y, xx) in enumerate(pos)])
+    got = host_conv(x, w, pos=pos, win=1, Hl=1, Wl=1, pos_mul=1)
+    assert np.abs(got - ref).max() < 1e-4
+
+
+def test_nearest_upsample_folded_into_conv():
+    x = RNG.normal(size=(2, 8, 15, 15)).astype(np.float32)
+    w = RNG.normal(size=(4, 8, 3, 3)).astype(np.float32)
+    for size in (31, 61):
+        ref = O.conv2d(O.upsample_nearest(x.astype(np.float64), size), w.astype(np.float64), None, 1, 1, 1)
+        got = host_conv(x, w, pad=1, ups=1, Hl=size, Wl=size)
+        assert np.abs(got - ref).max() < 1e-4
+
+
+def test_channel_slice():
+    x = RNG.normal(size=(1, 24, 6, 6)).astype(np.float32)
+    w = RNG.normal(size=(5, 8, 1, 1)).astype(np.float32)
+    ref = O.conv2d(x[:, 8:16].astype(np.float64), w.astype(np.float64))
+    got = host_conv(x, w, cin_off=8, cin_len=8)
+    assert np.abs(got - ref).max() < 1e-4
+
+
+def test_upsample_map_equals_torch():
+    """F.upsample(mode='nearest') index map == (dst*in)//out for the three sizes used."""
+    import torch
+    import torch.nn.functional as F
+    for hin, hout in ((15, 31), (31, 61), (61, 127)):
+        t = torch.arange(hin, dtype=torch.float32).view(1, 1, hin, 1).expand(1, 1, hin, hin).contiguous()
+        up = F.interpolate(t, size=(hout, hout), mode="nearest")[0, 0, :, 0].numpy().astype(int)
+        assert (up == (np.arange(hout) * hin) // hout).all()

@@ -54,3 +54,20 @@ def test_fixture_is_well_conditioned():
         g = load_golden(case)
         assert np.abs(g["cls"]).max() < 50 and np.abs(g["loc"]).max() < 50
         assert g["top2_gap"].min() > 1e-3
+
+
+def test_torch_port_matches_reference():
+    """The CPU-baseline port (oracle/torch_port.py, fp32) reproduces the reference's outputs
+    within the fp32 noise floor of the fixture (<= 8.4e-6 vs float64)."""
+    import torch
+    from oracle.torch_port import TorchPort
+    g = load_golden("sharp_damped_b2")
+    t = TorchPort(synth.state_dict("sharp", "synthetic_damped"), "sharp")
+    with torch.no_grad():
+        t.template(torch.from_numpy(g["z_u8"].astype(np.float32)))
+        cls, loc, mask = t.track_mask(torch.from_numpy(g["x_u8"].astype(np.float32)))
+        assert rel_err(cls.numpy(), g["cls"]) < 1e-4
+        assert rel_err(loc.numpy(), g["loc"]) < 1e-4
+        assert sampled_err(g, "mask", mask.numpy()) < 1e-4
+        shared = t.track_refine(tuple(int(v) for v in g["shared_pos"]))
+        assert rel_err(shared.numpy(), g["refine_shared"]) < 1e-4
