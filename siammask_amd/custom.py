@@ -218,6 +218,19 @@ class Custom(nn.Module):
         self._tracked = 0
         return cls, loc
 
+    # -- per-launch profiling (HIP events around every kernel; bypasses graph replay) -----------
+    def profile(self, enable=True):
+        if self._ctx is None:
+            raise RuntimeError("profile(): run template() first")
+        _lib.check(_lib.lib().smk_profile(self._ctx, 1 if enable else 0))
+
+    def profile_dump(self):
+        """-> list of {'id','kernel','calls','ms','flop','bytes'} (algorithmic work), then resets."""
+        import json
+        buf = ctypes.create_string_buffer(1 << 18)
+        _lib.check(_lib.lib().smk_profile_dump(self._ctx, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     def __repr__(self):
         return "%s(variant=%s, dtype=%s, graph=%s)" % (type(self).__name__, self.variant, self._dtype, self._graph)
 

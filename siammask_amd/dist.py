@@ -1,0 +1,81 @@
+"""Multi-GPU: independent video streams sharded over the GPUs of one node, one process per GPU.
+
+The path shards by stream: each (video, object) stream is independent, frames
+within a stream are sequential.  Every rank holds a full weight replica and tracks its own
+streams in lock-step batches; there is NO data-path collective.  The only exchange is one
+RCCL all_gather (torch.distributed backend 'nccl' == RCCL on ROCm) of the fixed-size results
+(boxes/scores and mask logits) at the end of a batch of frames, issued on a side stream so
+that it can overlap the next batch of frames.  With the 'gloo' backend the same code runs on
+CPU tensors (world_size-2 tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_streams(n_streams, rank, world):
+    """Round-robin assignment of stream ids to ranks -> list of global stream ids of `rank`."""
+    return list(range(rank, n_streams, world))
+
+
+def stream_owner(stream_id, world):
+    return stream_id % world
+
+
+class ResultGather(object):
+    """all_gather of per-rank results [S_local, T, ...] -> [world, S_local, T, ...] on every rank.
+
+    Every rank must contribute the same shapes (pad the last shard).  On GPUs the collective
+    runs on a dedicated side stream; ``wait()`` makes the current stream wait for it."""
+
+    def __init__(self, device=None):
+        self.device = device
+        self.side = torch.cuda.Stream(device=device) if (device is not None and device.type == "cuda") else None
+        self._pending = []
+
+    def gather(self, *tensors):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        outs = []
+        if world == 1:
+            return [t.unsqueeze(0) for t in tensors]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                for t in tensors:
+                    t = t.contiguous()
+                    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                    dist.all_gather_into_tensor(out, t)
+                    t.record_stream(self.side)
+                    outs.append(out)
+        else:
+            for t in tensors:
+                t = t.contiguous()
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                outs.append(torch.stack(parts))
+        return outs
+
+    def wait(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+def unshard(gathered, n_streams):
+    """[world, S_local, ...] gathered with round-robin sharding -> [n_streams, ...] in stream order."""
+    world, s_local = gathered.shape[0], gathered.shape[1]
+    flat = gathered.transpose(0, 1).reshape((world * s_local,) + tuple(gathered.shape[2:]))
+    return flat[:n_streams]
