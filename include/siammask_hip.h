@@ -106,6 +106,10 @@ int smk_refine(smk_ctx *ctx, const int32_t *pos_yx, int pos_on_device, int batch
  * I/O pointers), so keep the I/O buffers stable to hit the cache. */
 int smk_set_graph_mode(smk_ctx *ctx, int enable);
 
+/* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured
+ * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16". */
+int smk_tune(const char *key, int value);
+
 /* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the
  * stream it is launched on (graph replay is bypassed while profiling).  smk_profile_dump
  * synchronises the device and writes a JSON array, one object per layer id in launch order:

@@ -25,7 +25,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
     "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_graph_mode",
-    "smk_debug_read", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
+    "smk_debug_read", "smk_tune", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_host_conv2d_ex",
 )
 
@@ -77,6 +77,7 @@ def lib():
     L.smk_track.argtypes = [vp, fp, ci, ci, fp, fp, fp, vp]
     L.smk_refine.argtypes = [vp, vp, ci, ci, fp, vp]
     L.smk_set_graph_mode.argtypes = [vp, ci]
+    L.smk_tune.argtypes = [ctypes.c_char_p, ci]
     L.smk_profile.argtypes = [vp, ci]
     L.smk_profile_dump.argtypes = [vp, ctypes.c_char_p, ci]
     ip = ctypes.POINTER(ci)
@@ -103,3 +104,9 @@ def check(rc):
 
 def current_stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def tune(**kw):
+    """Set process-wide tuning knobs of the library (A/B measurements)."""
+    for k, v in kw.items():
+        check(lib().smk_tune(k.encode(), int(v)))

@@ -69,21 +69,35 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 
 template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
 
-template <typename T, int BM, int BN, int OUT_MODE>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// 16-byte direct-to-LDS load (LDS-DMA): lane l's 16 bytes land at lds_base + 16*l.
+// lds_base must be wave-uniform (it travels in M0); the global source is per lane.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t *)gsrc, (lds_void_t *)lds_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int OUT_MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     typedef Traits<T> TR;
     constexpr int VE = TR::VE;
     constexpr int BK = KTILE_BYTES / (int)sizeof(T);
     constexpr int FM = BM / 64, FN = BN / 64;     // 32x32 fragments per wave
-    constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte vectors per thread per K tile
+    constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte LDS-DMA pieces per thread per K tile
     constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
     constexpr int LDE = (OUT_MODE == OUT_NCHW_F32) ? WTN + 1 : WTN + 4;
     constexpr int STAGE_BYTES = (BM + BN) * KTILE_BYTES;
     constexpr int EPI_BYTES = 4 * WTM * LDE * 4;
-    constexpr int LDS_BYTES = CMax<2 * STAGE_BYTES, EPI_BYTES>::v;
+    constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = blockIdx.z;
     const int cin_off = p.cin_off + g * p.g_cin_off;
@@ -91,10 +105,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const float *bias = p.bias + g * p.g_wgt_off;
     const int cout_off = p.cout_off + g * p.g_cout_off;
 
+    // XCD-aware tile order (p.xcd_mode): workgroup b runs on XCD b % 8 (observed dispatch
+    // order, used for speed only).  Mode 1 hands every XCD a contiguous range of the tm-major
+    // tile sequence, so the workgroups sharing one activation row panel (same tm, all tn) run
+    // on ONE XCD and that panel is fetched into one L2 only.
     const int tilesN = (p.Nst + BN - 1) / BN;
-    const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+    int t = blockIdx.x;
+    if (p.xcd_mode != 0) {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int x = t & 7, j = t >> 3;
+        t = x * q + (x < r ? x : r) + j;
+    }
+    int tm, tn;
+    if (p.xcd_mode == 2) {            // tn-major: each XCD owns a range of weight panels
+        const int tilesM = (p.M + BM - 1) / BM;
+        tn = t / tilesM; tm = t - tn * tilesM;
+    } else {
+        tm = t / tilesN; tn = t - tm * tilesN;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int slot = tid & 7, lrow = tid >> 3;
+
+    // LDS-DMA writes lane-linear: lane l of wave w fills (row 8w + l/8 [+32i], physical slot l%8).
+    // The XOR swizzle therefore goes on the SOURCE: this thread fetches the logical 16-byte
+    // slot  phys ^ ((row>>1)&7)  of its row, and the fragment reads apply the same XOR.
+    const int lrow = tid >> 3;
+    const int slot = (tid & 7) ^ ((lrow >> 1) & 7);
 
     // ---- per-thread row bookkeeping for the A gather --------------------------------------
     RowInfo ri[RA];
@@ -105,34 +140,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         rvalid[i] = m < p.M;
         ri[i] = row_info(p, rvalid[i] ? m : 0, p.pos);
     }
-    const T *wrow[RB];
+    const char *in = (const char *)p.in;
+    const long zero_off = (const char *)p.zero - in;   // 8 KB of zeros: source of all padding
+    const char *wsrc[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) wrow[i] = wgt + (size_t)(n0 + lrow + 32 * i) * p.Kpad;
-
-    const T *in = (const T *)p.in;
+    for (int i = 0; i < RB; ++i)
+        wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + 32 * i) * p.Kpad + slot * VE);
     const int nk = (p.K + BK - 1) / BK;
 
-    uint4 ra[RA], rb[RB];
-    auto load_tile = [&](int kt) {
-        const int kvec = kt * BK + slot * VE;
-        const bool kvalid = kvec < p.K;
-        const KDecode d = decode_k(kvec, p.Ci, p.kw);
+    // This thread always fetches the same 16-byte slot of every K tile, i.e. K index
+    // kt*BK + slot*VE.  Its (tap, channel) position advances incrementally; the per-row source
+    // offsets are recomputed only when the tap changes (once per Ci/BK tiles on the heavy
+    // layers), which keeps the address VALU work out of the MFMA loop.  Padding (conv zero
+    // padding, rows >= M, K tail) reads the zero page, so the loads are branch-free.
+    KDecode kd = decode_k(slot * VE, p.Ci, p.kw);
+    long a_off[RA];                                    // byte offsets relative to `in`
+    auto tap_offsets = [&]() {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            long off = (kvalid && rvalid[i]) ? gather_offset(p, ri[i], d, cin_off) : -1;
-            if (off >= 0) ra[i] = *(const uint4 *)(in + off);
-            else ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            long off = -1;
+            if (rvalid[i] && kd.kh_i < p.kh) {
+                KDecode d0 = kd;
+                d0.c = 0;
+                off = gather_offset(p, ri[i], d0, cin_off);
+            }
+            a_off[i] = off >= 0 ? off * (long)sizeof(T) : zero_off;
         }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = *(const uint4 *)(wrow[i] + kvec);
     };
-    auto store_tile = [&](int buf) {
-        unsigned char *sA = smem + buf * STAGE_BYTES;
+    tap_offsets();
+    auto advance = [&]() {
+        kd.c += BK;
+        if (kd.c >= p.Ci) {
+            do {
+                kd.c -= p.Ci;
+                if (++kd.kw_i == p.kw) { kd.kw_i = 0; ++kd.kh_i; }
+            } while (kd.c >= p.Ci);
+            tap_offsets();
+        }
+    };
+    // issue the LDS-DMA of K tile kt into ring slot `buf` (RA + RB loads per thread)
+    auto issue = [&](int kt, int buf) {
+        unsigned char *sA = smem + buf * STAGE_BYTES + wave * (8 * KTILE_BYTES);
         unsigned char *sB = sA + BM * KTILE_BYTES;
+        const long cb = (long)kd.c * (long)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *(uint4 *)(sA + lds_off(lrow + 32 * i, slot)) = ra[i];
+        for (int i = 0; i < RA; ++i) glds16(in + a_off[i] + cb, sA + i * (32 * KTILE_BYTES));
+        const long kb = (long)kt * KTILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *(uint4 *)(sB + lds_off(lrow + 32 * i, slot)) = rb[i];
+        for (int i = 0; i < RB; ++i) glds16(wsrc[i] + kb, sB + i * (32 * KTILE_BYTES));
     };
 
     floatx16 acc[FM][FN];
@@ -143,15 +198,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // ---- prologue: NSTAGE-1 tiles in flight --------------------------------------------------
+    issue(0, 0);
+    if (NSTAGE == 3 && nk > 1) { advance(); issue(1, 1); }
 
     const int frow = lane & 31, fhalf = lane >> 5;
+    int cur = 0;                       // ring slot holding tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
+        // my pieces of tile kt have landed (tiles issued after it may still be in flight) ...
+        if (NSTAGE == 3 && kt + 1 < nk) wait_vmcnt<RA + RB>();
+        else wait_vmcnt<0>();
+        // ... and so have everybody else's; all waves are also done reading the slot refilled below
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int ahead = NSTAGE - 1;
+        if (kt + ahead < nk) {
+            int nxt = cur + ahead;
+            if (nxt >= NSTAGE) nxt -= NSTAGE;
+            advance();
+            issue(kt + ahead, nxt);
+        }
         const unsigned char *sA = smem + cur * STAGE_BYTES;
         const unsigned char *sB = sA + BM * KTILE_BYTES;
 #pragma unroll
@@ -169,9 +235,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) TR::mma(acc[i][j], a[i], b[j]);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
+        if (++cur == NSTAGE) cur = 0;
     }
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (per-wave region) -> fused bias/res/relu -> global ---
     float *e = (float *)smem + wave * (WTM * LDE);
@@ -289,9 +355,16 @@ __global__ void conv_naive_kernel(const ConvParams p) {
 
 // ---- dispatch ------------------------------------------------------------------------------
 static int g_num_cu = 256;
+Tuning g_tune;
 
 TileChoice choose_tile(const ConvParams &p, int dtype) {
     (void)dtype;
+    if (g_tune.force_tile) {
+        static const int tb[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+        TileChoice f{tb[g_tune.force_tile][0], tb[g_tune.force_tile][1]};
+        if (p.Nst <= 64) f.bn = 64;
+        return f;
+    }
     auto blocks = [&](int bm, int bn) {
         return (long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * (p.groups > 0 ? p.groups : 1);
     };
@@ -299,8 +372,9 @@ TileChoice choose_tile(const ConvParams &p, int dtype) {
     t.bn = p.Nst > 64 ? 128 : 64;
     t.bm = p.M > 64 ? 128 : 64;
     // keep every CU busy: shrink the tile while the grid is smaller than the chip
-    if (blocks(t.bm, t.bn) < g_num_cu && t.bm == 128) t.bm = 64;
-    if (blocks(t.bm, t.bn) < g_num_cu && t.bn == 128) t.bn = 64;
+    const long want = (long)g_num_cu * g_tune.min_blocks_x16 / 16;
+    if (blocks(t.bm, t.bn) < want && t.bm == 128) t.bm = 64;
+    if (blocks(t.bm, t.bn) < want && t.bn == 128) t.bn = 64;
     return t;
 }
 
@@ -308,7 +382,11 @@ template <typename T, int BM, int BN, int OM>
 static int launch_one(const ConvParams &p, hipStream_t s) {
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Nst + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, OM>), grid, dim3(256), 0, s, p);
+    // ring depth: 128x128 tiles run 2 stages (64 KB -> two workgroups per CU overlap each other),
+    // smaller tiles 3 stages (two K tiles in flight per workgroup); measured, see DESIGN.md
+    const int stages = g_tune.stages ? g_tune.stages : ((BM == 128 && BN == 128) ? 2 : 3);
+    if (stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, OM, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, OM, 3>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -57,6 +57,23 @@ static int fail(int code, const char *fmt, ...) {
 
 static inline int rup(int x, int a) { return (x + a - 1) / a * a; }
 
+// 8 KB of zeros per device: every padded tap / out-of-range row / K tail of the conv kernel's
+// LDS-DMA gather reads from here, which keeps the loads branch-free.
+namespace smk {
+const void *zero_page() {
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 16384) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 16384) != hipSuccess) return nullptr;
+        pages[dev] = p;
+    }
+    return pages[dev];
+}
+}  // namespace smk
+
 // ---------------------------------------------------------------------------------------------
 // weights
 // ---------------------------------------------------------------------------------------------
@@ -448,6 +465,9 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         if (o.cout_off + (o.groups - 1) * pc.group_rows + p.Nst > out->C)
             return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
     }
+    p.xcd_mode = g_tune.xcd_mode;
+    p.zero = c->device >= 0 ? zero_page() : nullptr;      // device < 0: host-side walk (CPU tests)
+    if (c->device >= 0 && !p.zero) return fail(SMK_E_HIP, "could not allocate the zero page");
     if (o.res) {
         p.res = o.res->p;
         p.res_Cs = o.res->C;
@@ -722,6 +742,7 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     c->graph_mode = g && strcmp(g, "0") != 0;
     int rc = build_arena(c.get());
     if (rc) return rc;
+    if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
     *out = c.release();
     return 0;
 }
@@ -825,6 +846,16 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
     }
     GraphKey key{2, B, 0, out, nullptr, nullptr, nullptr};
     return run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_refine(c, B, out, st); });
+}
+
+int smk_tune(const char *key, int value) {
+    if (!key) return fail(SMK_E_ARG, "smk_tune: key is NULL");
+    if (!strcmp(key, "xcd_mode")) g_tune.xcd_mode = value;
+    else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 4) return fail(SMK_E_ARG, "force_tile 0..4"); g_tune.force_tile = value; }
+    else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
+    else if (!strcmp(key, "stages")) { if (value != 0 && value != 2 && value != 3) return fail(SMK_E_ARG, "stages 0|2|3"); g_tune.stages = value; }
+    else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
+    return 0;
 }
 
 int smk_profile(smk_ctx *c, int enable) {
@@ -977,6 +1008,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     }
     smk_ctx fake;
     fake.dtype = dtype;
+    HIPCHK(hipGetDevice(&fake.device));
     ConvParams p;
     if (nchw) {
         o.nchw_out = y_dev;
@@ -1075,6 +1107,7 @@ int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, c
     std::vector<float> obuf((size_t)g->B * Ho * Wo * out.C, 0.f);
     out.p = obuf.data();
     smk_ctx fake;
+    fake.device = -1;
     ConvParams p;
     CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
     for (int m = 0; m < p.M; ++m) {

@@ -28,6 +28,7 @@ struct ConvParams {
     const void *res;       // optional residual, NHWC [B][Ho][Wo][res_Cs] (dtype)
     void *out;             // NHWC dtype  or  NCHW f32
     const int *pos;        // optional per-item (y,x) pairs selecting the window origin
+    const void *zero;      // >= 8 KB of zeros in device memory (source of all zero padding)
     int B;
     int Hs, Ws, Cs;        // storage dims of the input, channel stride per pixel
     int cin_off;           // first channel of the slice that is read
@@ -50,7 +51,17 @@ struct ConvParams {
     int g_cin_off;         // added to cin_off
     int g_wgt_off;         // rows of wgt/bias per group (multiple of NPAD_ALIGN)
     int g_cout_off;        // added to cout_off
+    int xcd_mode;          // 0: tiles in launch order, 1: XCD-contiguous tm-major, 2: tn-major
 };
+
+// run-time tuning knobs (smk_tune): measured defaults, overridable for A/B runs
+struct Tuning {
+    int xcd_mode = 1;
+    int force_tile = 0;        // 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64
+    int min_blocks_x16 = 16;   // shrink tiles while grid < CUs * min_blocks_x16/16
+    int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2 or 3
+};
+extern Tuning g_tune;
 
 // decode a K index (start of a 16-byte vector) into tap + channel
 struct KDecode { int kh_i, kw_i, c; };
@@ -123,5 +134,6 @@ int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
+const void *zero_page();   // device-resident 8 KB of zeros (allocated on first use, per device)
 
 }  // namespace smk
