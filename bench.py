@@ -57,7 +57,7 @@ def make_model(variant, dtype, batch, device):
 
 
 class Workload(object):
-    def __init__(self, name, device, rank, n_inputs=4, batch=None):
+    def __init__(self, name, device, rank, n_inputs=4, batch=None, fused=True):
         self.variant, self.B, self.dtype, self.refine = WORKLOADS[name]
         if batch:
             self.B = batch
@@ -71,13 +71,22 @@ class Workload(object):
                    for i in range(n_inputs)]
         g = np.random.Generator(np.random.PCG64(99 + rank))
         self.pos = torch.from_numpy(g.integers(8, 17, size=(B, 2)).astype(np.int32)).to(device)
+        # target size in crop pixels per stream (what siamese_track derives from its state)
+        self.twh = torch.from_numpy(g.uniform(40.0, 110.0, size=(B, 2)).astype(np.float32)).to(device)
         self.model.template(self.z)
+        self.fused = fused
         self.last = None
 
     def step(self, i):
+        """One frame per stream.  fused: track_mask -> on-device decode (tools/test.py:205-254) ->
+        track_refine at the decoded positions, one captured graph, no host round trip.
+        unfused: the reference's call sequence with a fixed refine position."""
         m = self.model
         x = self.xs[i % len(self.xs)]
-        if self.variant == "rpn":
+        if self.fused:
+            o = m.track_step(x, self.twh, refine=self.refine)
+            self.last = (o["cls"], o["loc"], o["mask"], o["refine"])
+        elif self.variant == "rpn":
             cls, loc = m.track(x)
             self.last = (cls, loc, None, None)
         else:
@@ -223,6 +232,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads (B=1 fp32, ...)")
     ap.add_argument("--prewarm-seconds", type=float, default=2.0,
                     help="untimed clock/cache warm-up before the W warm-up steps")
+    ap.add_argument("--unfused", action="store_true",
+                    help="time the reference call sequence (track_mask, track_refine(fixed pos)) instead of the "
+                         "fused device-resident step")
     ap.add_argument("--tune", default="", help="library tuning knobs, e.g. xcd_mode=0,force_tile=1")
     ap.add_argument("--profile-out", default="", help="write the per-layer launch profile (JSON) here")
     args = ap.parse_args()
@@ -237,7 +249,7 @@ def main():
     torch.cuda.set_device(dev)
     gather = sdist.ResultGather(dev)
 
-    w = Workload(args.workload, dev, rank, batch=args.batch)
+    w = Workload(args.workload, dev, rank, batch=args.batch, fused=not args.unfused)
     prewarm(w, args.prewarm_seconds)
     dt = timed_run(w, args.steps, args.warmup, world, gather)
     frames = w.B * world * args.steps
@@ -283,6 +295,8 @@ def main():
                        "name": args.workload, "variant": w.variant, "batch_per_gpu": w.B,
                        "global_batch": w.B * world, "parallelism": "streams sharded x%d" % world,
                        "weights": "synthetic_damped (calibrated random init)", "graph": True,
+                       "step": ("track_mask -> device decode -> track_refine, one graph" if w.fused
+                                else "track_mask ; track_refine(fixed pos)"),
                        "gflop_per_frame": w.gflop_per_frame()},
             "roofline": roof,
             "cpu_baseline": cpu,

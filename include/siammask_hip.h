@@ -101,13 +101,35 @@ int smk_track(smk_ctx *ctx, const float *x_dev, int batch, int flags,
 int smk_refine(smk_ctx *ctx, const int32_t *pos_yx, int pos_on_device, int batch,
                float *out, void *stream);
 
+/* ---- on-device decode (additive: the tools keep using cls/loc as before) ----
+ * smk_decode restates the host code of tools/test.py:205-254 per stream on the device:
+ * softmax foreground score, anchor decode (utils/anchors.py:28-51), scale/ratio penalty, cosine
+ * window, argmax (lowest index wins ties, like np.argmax), in float64.
+ *   target_wh [B,2] device f32: target size in crop pixels (w,h) = target_sz * scale_x (:230)
+ *   pos_out   [B,2] device int32 (y,x) = unravel_index(best,(5,25,25))[1:] (:253-254); NULL =
+ *             only the ctx-internal position used by a following smk_refine/smk_step is set
+ *   box_out   [B,8] device f32: cx, cy, w, h in crop pixels (delta[:,best], :209-212), score,
+ *             penalty, pscore, best_id
+ * smk_set_decode_params: anchor (w,h) pairs (5), stride, hp penalty_k / window_influence
+ * (config_davis.json); defaults are the reference's config.
+ * smk_step = smk_track + smk_decode + smk_refine(at the decoded positions) as ONE captured
+ * graph: no host round trip inside a frame.  refine_out may be NULL (no Refine). */
+int smk_set_decode_params(smk_ctx *ctx, const float *anchor_wh, int n_anchor, int stride,
+                          double penalty_k, double window_influence);
+int smk_decode(smk_ctx *ctx, const float *cls_dev, const float *loc_dev, int batch,
+               const float *target_wh_dev, int32_t *pos_out_dev, float *box_out_dev, void *stream);
+int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const float *target_wh_dev,
+             float *cls_out, float *loc_out, float *mask_out, float *box_out, float *refine_out,
+             void *stream);
+
 /* capture the launch sequences into hipGraphs and replay them (on by default when the
  * environment variable SMK_GRAPH is not "0"); graphs are keyed on (entry, batch, flags,
  * I/O pointers), so keep the I/O buffers stable to hit the cache. */
 int smk_set_graph_mode(smk_ctx *ctx, int enable);
 
 /* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured
- * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16". */
+ * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16", "stages" 0|2|3, "concurrency" 0|1
+ * (the latter applies to contexts created afterwards). */
 int smk_tune(const char *key, int value);
 
 /* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the

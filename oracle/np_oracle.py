@@ -323,4 +323,6 @@ def decode_best(cls, loc, target_sz=(60.0, 80.0), scale_x=1.0, penalty_k=0.04,
     pscore = pscore * (1 - window_influence) + window * window_influence
     best = int(np.argmax(pscore))
     _, dy, dx = np.unravel_index(best, (5, score_size, score_size))
+    decode_best.last = {"box": np.array([delta[0, best], delta[1, best], delta[2, best], delta[3, best],
+                                          score[best], penalty[best], pscore[best], best], dtype=np.float64)}
     return best, int(dy), int(dx), pscore

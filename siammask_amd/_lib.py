@@ -24,7 +24,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 # every symbol include/siammask_hip.h declares
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
-    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_graph_mode",
+    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode",
     "smk_debug_read", "smk_tune", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_host_conv2d_ex",
 )
@@ -76,6 +76,9 @@ def lib():
     L.smk_template.argtypes = [vp, fp, ci, vp]
     L.smk_track.argtypes = [vp, fp, ci, ci, fp, fp, fp, vp]
     L.smk_refine.argtypes = [vp, vp, ci, ci, fp, vp]
+    L.smk_set_decode_params.argtypes = [vp, fp, ci, ci, ctypes.c_double, ctypes.c_double]
+    L.smk_decode.argtypes = [vp, fp, fp, ci, fp, vp, fp, vp]
+    L.smk_step.argtypes = [vp, fp, ci, ci, fp, fp, fp, fp, fp, fp, vp]
     L.smk_set_graph_mode.argtypes = [vp, ci]
     L.smk_tune.argtypes = [ctypes.c_char_p, ci]
     L.smk_profile.argtypes = [vp, ci]

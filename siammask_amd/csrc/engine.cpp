@@ -30,6 +30,7 @@ using namespace smk;
 // errors
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static int g_concurrency_default = 0;   // measured slower on MI355X (cross-stream graph edges), see DESIGN.md
 
 static int fail(int code, const char *fmt, ...) {
     char buf[1024];
@@ -138,7 +139,7 @@ struct Act {
     int H = 0, W = 0, C = 0;   // C = channel stride
 };
 
-typedef std::tuple<int, int, int, const void *, const void *, const void *, const void *> GraphKey;
+typedef std::tuple<int, int, int, std::vector<const void *>> GraphKey;
 
 struct smk_ctx {
     int device = 0, dtype = DT_F32, variant = SMK_VARIANT_SHARP, maxB = 1;
@@ -157,6 +158,18 @@ struct smk_ctx {
     std::map<std::string, void *> buf;
     std::map<std::string, size_t> buf_elems;  // per item
     int *pos_dev = nullptr;
+
+    // decode (tools/test.py:205-254 on device)
+    float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
+    int anchor_stride = 8;
+    double *window_dev = nullptr;        // [25*25] outer(hanning(25), hanning(25))
+    double penalty_k = 0.04, window_influence = 0.4;   // config_davis.json hp
+
+    // fork/join concurrency between independent launches (side streams + event pool)
+    bool concurrency = true;
+    hipStream_t side[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
 
     // per-launch profiling (smk_profile): HIP events around every kernel, eager mode only
     bool prof = false;
@@ -179,6 +192,15 @@ struct ProfScope {
     }
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, s); }
 };
+
+// make `to` wait for everything enqueued so far on `from` (captured as a graph dependency)
+static int stream_dep(smk_ctx *c, hipStream_t from, hipStream_t to) {
+    hipEvent_t e = c->ev_pool[c->ev_next++ % c->ev_pool.size()];
+    HIPCHK(hipEventRecord(e, from));
+    HIPCHK(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+static bool parallel_ok(const smk_ctx *c) { return c->concurrency && !c->prof && c->side[0] && c->side[1]; }
 
 static int nbranch(const smk_ctx *c) { return c->variant == SMK_VARIANT_RPN ? 2 : 3; }
 
@@ -556,19 +578,24 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             Act t1 = act(c, "t1", sp, sp, planes);
             Act t2 = act(c, "t2", so, so, planes);
             ConvOpt o1; o1.relu = 1;
-            CHK(run_conv(c, (id + "c1").c_str(), cur, &t1, B, o1, s));
             ConvOpt o2; o2.relu = 1; o2.stride = stride; o2.pad = pad2; o2.dil = dil;
-            CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
             Act res = cur;
+            const bool par = parallel_ok(c);
             if (b == 0) {
+                // the shortcut conv only depends on the block input: run it beside conv1->conv2
                 Act r = act(c, "r", so, so, planes * 4);
                 ConvOpt od;
                 if (st == 0) { od.stride = 1; od.pad = 0; }          // 1x1
                 else if (st == 1) { od.stride = 2; od.pad = 0; }     // 3x3 s2 p0
                 else { od.stride = 1; od.pad = 1; }                  // 3x3 s1 p1
-                CHK(run_conv(c, (id + "ds").c_str(), cur, &r, B, od, s));
+                hipStream_t sd = par ? c->side[0] : s;
+                if (par) CHK(stream_dep(c, s, sd));
+                CHK(run_conv(c, (id + "ds").c_str(), cur, &r, B, od, sd));
                 res = r;
             }
+            CHK(run_conv(c, (id + "c1").c_str(), cur, &t1, B, o1, s));
+            CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
+            if (b == 0 && par) CHK(stream_dep(c, c->side[0], s));
             const bool last = b == STAGE_BLOCKS[st] - 1;
             const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : "a") : ((b & 1) ? "b" : "a");
             if (last && st == 2 && cur.p == c->buf.at("a")) oname = "b";
@@ -623,14 +650,20 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     Act h0 = act(c, "head0", 25, 25, 256 * nbt);
     ConvOpt oh; oh.relu = 1; oh.groups = nb;                      // head.0 1x1 + BN + ReLU per branch
     CHK(run_conv(c, "head0", corr, &h0, B, oh, s));
+    // the three head.3 convs are independent: cls / loc / mask side by side
+    const bool par = parallel_ok(c);
+    const bool want_mask = (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD);
+    hipStream_t s_loc = par ? c->side[0] : s, s_cls = (par && want_mask) ? c->side[1] : s;
+    if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
-    CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s));
+    CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
     ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
-    CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s));
-    if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD)) {
+    CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
+    if (want_mask) {
         ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
         CHK(run_conv(c, "mask3", h0, nullptr, B, om, s));
     }
+    if (par) { CHK(stream_dep(c, s_loc, s)); if (s_cls != s) CHK(stream_dep(c, s_cls, s)); }
     c->last_nb = nb;
     return 0;
 }
@@ -640,19 +673,40 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     const int *pos = c->pos_dev;
     Act corr = act(c, "corr", 25, 25, 256 * 3);
     Act p0 = act(c, "p0", 125, 125, 64), p1 = act(c, "p1", 63, 63, 256), p2 = act(c, "p2", 31, 31, 512);
+    // The three window convs v2.0 / v1.0 / v0.0 (the heavy part of Refine) depend only on the
+    // kept backbone features and pos: they run on a side stream beside deconv -> h2 -> ...
+    ConvOpt r3; r3.pad = 1; r3.relu = 1;
+    ConvOpt w2 = r3; w2.win = true; w2.Hl = w2.Wl = 15; w2.pos = pos; w2.pos_mul = 1; w2.pos_add = -4;   // pad 4 (:135)
+    ConvOpt w1 = r3; w1.win = true; w1.Hl = w1.Wl = 31; w1.pos = pos; w1.pos_mul = 2; w1.pos_add = -8;   // pad 8 (:134)
+    ConvOpt w0 = r3; w0.win = true; w0.Hl = w0.Wl = 61; w0.pos = pos; w0.pos_mul = 4; w0.pos_add = -16;  // pad 16 (:133)
+    const bool par = parallel_ok(c);
+    hipEvent_t ev_v2 = nullptr, ev_v1 = nullptr, ev_v0 = nullptr;
+    if (par) {
+        hipStream_t sd = c->side[0];
+        CHK(stream_dep(c, s, sd));
+        Act v2a_ = act(c, "rf_v2a", 15, 15, 128), v1a_ = act(c, "rf_v1a", 31, 31, 64), v0a_ = act(c, "rf_v0a", 61, 61, 16);
+        CHK(run_conv(c, "v2.0", p2, &v2a_, B, w2, sd));
+        ev_v2 = c->ev_pool[c->ev_next++ % c->ev_pool.size()];
+        HIPCHK(hipEventRecord(ev_v2, sd));
+        CHK(run_conv(c, "v1.0", p1, &v1a_, B, w1, sd));
+        ev_v1 = c->ev_pool[c->ev_next++ % c->ev_pool.size()];
+        HIPCHK(hipEventRecord(ev_v1, sd));
+        CHK(run_conv(c, "v0.0", p0, &v0a_, B, w0, sd));
+        ev_v0 = c->ev_pool[c->ev_next++ % c->ev_pool.size()];
+        HIPCHK(hipEventRecord(ev_v0, sd));
+    }
     // deconv(corr_feature[:, :, y, x]) -> [15,15,32]            (:145,:149)
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
     ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
     CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
     Act d = act(c, "rf_d", 15, 15, 32);
-    ConvOpt r3; r3.pad = 1; r3.relu = 1;
     // stage 2 @15x15                                             (:150)
     Act h2a = act(c, "rf_h2a", 15, 15, 32), h2b = act(c, "rf_h2b", 15, 15, 32);
     CHK(run_conv(c, "h2.0", d, &h2a, B, r3, s));
     CHK(run_conv(c, "h2.2", h2a, &h2b, B, r3, s));
     Act v2a = act(c, "rf_v2a", 15, 15, 128), s2 = act(c, "rf_s2", 15, 15, 32);
-    ConvOpt w2 = r3; w2.win = true; w2.Hl = w2.Wl = 15; w2.pos = pos; w2.pos_mul = 1; w2.pos_add = -4;   // pad 4 (:135)
-    CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
+    if (par) CHK(hipStreamWaitEvent(s, ev_v2, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v2"));
+    else CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
     ConvOpt a2 = r3; a2.res = &h2b; a2.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v2.2", v2a, &s2, B, a2, s));
     Act u0 = act(c, "rf_u0", 31, 31, 16);
@@ -663,8 +717,8 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     CHK(run_conv(c, "h1.0", u0, &h1a, B, r3, s));
     CHK(run_conv(c, "h1.2", h1a, &h1b, B, r3, s));
     Act v1a = act(c, "rf_v1a", 31, 31, 64), s1 = act(c, "rf_s1", 31, 31, 16);
-    ConvOpt w1 = r3; w1.win = true; w1.Hl = w1.Wl = 31; w1.pos = pos; w1.pos_mul = 2; w1.pos_add = -8;   // pad 8 (:134)
-    CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
+    if (par) CHK(hipStreamWaitEvent(s, ev_v1, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v1"));
+    else CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
     ConvOpt a1 = r3; a1.res = &h1b; a1.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v1.2", v1a, &s1, B, a1, s));
     Act u1 = act(c, "rf_u1", 61, 61, 8);
@@ -675,8 +729,8 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     CHK(run_conv(c, "h0.0", u1, &h0a, B, r3, s));
     CHK(run_conv(c, "h0.2", h0a, &h0b, B, r3, s));
     Act v0a = act(c, "rf_v0a", 61, 61, 16), s0 = act(c, "rf_s0", 61, 61, 8);
-    ConvOpt w0 = r3; w0.win = true; w0.Hl = w0.Wl = 61; w0.pos = pos; w0.pos_mul = 4; w0.pos_add = -16;  // pad 16 (:133)
-    CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
+    if (par) CHK(hipStreamWaitEvent(s, ev_v0, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v0"));
+    else CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
     ConvOpt a0 = r3; a0.res = &h0b; a0.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v0.2", v0a, &s0, B, a0, s));
     ConvOpt pu2; pu2.pad = 1; pu2.ups = true; pu2.Hl = pu2.Wl = 127; pu2.nchw_out = out;
@@ -743,6 +797,19 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     int rc = build_arena(c.get());
     if (rc) return rc;
     if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+    c->ev_pool.resize(64);
+    for (auto &e : c->ev_pool) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {
+        const char *cc = getenv("SMK_CONCURRENCY");
+        c->concurrency = !(cc && !strcmp(cc, "0")) && g_concurrency_default != 0;
+        double w[625], h[25];
+        for (int i = 0; i < 25; ++i) h[i] = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / 24.0);   // np.hanning(25)
+        for (int y = 0; y < 25; ++y)
+            for (int x = 0; x < 25; ++x) w[y * 25 + x] = h[y] * h[x];                      // np.outer
+        HIPCHK(hipMalloc((void **)&c->window_dev, sizeof(w)));
+        HIPCHK(hipMemcpy(c->window_dev, w, sizeof(w), hipMemcpyHostToDevice));
+    }
     *out = c.release();
     return 0;
 }
@@ -755,6 +822,9 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->buf) hipFree(kv.second);
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
+    if (c->window_dev) hipFree(c->window_dev);
+    for (auto &e : c->ev_pool) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (c->side[i]) hipStreamDestroy(c->side[i]);
     delete c;
     return 0;
 }
@@ -802,7 +872,7 @@ int smk_template(smk_ctx *c, const float *z, int B, void *stream) {
     if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_template: batch %d not in [1,%d]", B, c->maxB);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    GraphKey key{0, B, 0, z, nullptr, nullptr, nullptr};
+    GraphKey key{0, B, 0, {z}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_template(c, z, B, st); });
     if (rc) return rc;
     c->template_B = B;
@@ -823,7 +893,7 @@ int smk_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *l
         return fail(SMK_E_ARG, "smk_track: mask_out is NULL");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    GraphKey key{1, B, flags, x, cls, loc, mask};
+    GraphKey key{1, B, flags, {x, cls, loc, mask}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_track(c, x, B, flags, cls, loc, mask, st); });
     if (rc) return rc;
     c->track_B = (flags & SMK_TRACK_MASK) ? B : 0;
@@ -844,7 +914,7 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
     } else {
         HIPCHK(hipMemcpyAsync(c->pos_dev, pos, sizeof(int) * 2 * B, hipMemcpyDeviceToDevice, s));
     }
-    GraphKey key{2, B, 0, out, nullptr, nullptr, nullptr};
+    GraphKey key{2, B, 0, {out}};
     return run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_refine(c, B, out, st); });
 }
 
@@ -853,6 +923,7 @@ int smk_tune(const char *key, int value) {
     if (!strcmp(key, "xcd_mode")) g_tune.xcd_mode = value;
     else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 4) return fail(SMK_E_ARG, "force_tile 0..4"); g_tune.force_tile = value; }
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
+    else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && value != 2 && value != 3) return fail(SMK_E_ARG, "stages 0|2|3"); g_tune.stages = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
     return 0;
@@ -894,6 +965,69 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
     js += "]";
     if ((int)js.size() + 1 > cap) return fail(SMK_E_ARG, "smk_profile_dump: buffer too small (%zu needed)", js.size() + 1);
     memcpy(buf, js.c_str(), js.size() + 1);
+    return 0;
+}
+
+static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, const float *target_wh, int *pos_out,
+                      float *box_out, hipStream_t s) {
+    DecodeParams p;
+    memset(&p, 0, sizeof(p));
+    p.cls = cls; p.loc = loc; p.target_wh = target_wh; p.window = c->window_dev;
+    p.pos_out = pos_out; p.box_out = box_out;
+    p.B = B; p.A = 5; p.S = 25; p.stride = c->anchor_stride;
+    for (int i = 0; i < 5; ++i) { p.anchor_w[i] = c->anchor_w[i]; p.anchor_h[i] = c->anchor_h[i]; }
+    p.penalty_k = c->penalty_k; p.window_influence = c->window_influence;
+    ProfScope ps(c, s, "decode", "decode", 0.0, (double)B * 30 * 625 * 4);
+    if (launch_decode(p, s)) return fail(SMK_E_HIP, "decode launch failed");
+    return 0;
+}
+
+int smk_set_decode_params(smk_ctx *c, const float *anchor_wh, int n_anchor, int stride, double penalty_k,
+                          double window_influence) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    if (anchor_wh) {
+        if (n_anchor != 5) return fail(SMK_E_ARG, "smk_set_decode_params: kernels are specialised for 5 anchors");
+        for (int i = 0; i < 5; ++i) { c->anchor_w[i] = anchor_wh[2 * i]; c->anchor_h[i] = anchor_wh[2 * i + 1]; }
+    }
+    if (stride > 0) c->anchor_stride = stride;
+    c->penalty_k = penalty_k;
+    c->window_influence = window_influence;
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);   // hp are baked into captured launches
+    c->graphs.clear();
+    return 0;
+}
+
+int smk_decode(smk_ctx *c, const float *cls, const float *loc, int B, const float *target_wh, int32_t *pos_out,
+               float *box_out, void *stream) {
+    if (!c || !cls || !loc || !target_wh) return fail(SMK_E_ARG, "smk_decode: null argument");
+    if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_decode: batch %d not in [1,%d]", B, c->maxB);
+    HIPCHK(hipSetDevice(c->device));
+    return seq_decode(c, cls, loc, B, target_wh, pos_out ? pos_out : c->pos_dev, box_out, (hipStream_t)stream);
+}
+
+int smk_step(smk_ctx *c, const float *x, int B, int flags, const float *target_wh, float *cls, float *loc,
+             float *mask, float *box_out, float *refine_out, void *stream) {
+    if (!c || !x || !cls || !loc || !target_wh || !box_out) return fail(SMK_E_ARG, "smk_step: null argument");
+    if (!c->finalized) return fail(SMK_E_STATE, "smk_step: weights not finalized");
+    if (c->template_B == 0) return fail(SMK_E_STATE, "smk_step: smk_template has not been called");
+    if (B != c->template_B) return fail(SMK_E_ARG, "smk_step: batch %d != template batch %d", B, c->template_B);
+    if (refine_out && (c->variant != SMK_VARIANT_SHARP || !(flags & SMK_TRACK_MASK)))
+        return fail(SMK_E_ARG, "smk_step: refine needs the sharp variant and SMK_TRACK_MASK");
+    if ((flags & SMK_TRACK_MASK) && c->variant == SMK_VARIANT_RPN) return fail(SMK_E_ARG, "smk_step: rpn has no mask branch");
+    if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) && !mask) return fail(SMK_E_ARG, "smk_step: mask_out is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    int64_t pk, wi;
+    memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
+    GraphKey key{3, B, flags, {x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi}};
+    int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) {
+        CHK(seq_track(c, x, B, flags, cls, loc, mask, st));
+        CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
+        if (refine_out) CHK(seq_refine(c, B, refine_out, st));
+        return 0;
+    });
+    if (rc) return rc;
+    c->track_B = (flags & SMK_TRACK_MASK) ? B : 0;
     return 0;
 }
 

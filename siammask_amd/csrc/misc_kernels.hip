@@ -242,4 +242,78 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// ------------------------------------------------------------------------------------------
+// decode: softmax foreground score, anchor decode, scale/ratio penalty, cosine window, argmax.
+// Restates the host code of tools/test.py:205-254 (+ anchors of utils/anchors.py:28-51) per
+// stream, in float64 (NumPy >= 2 promotes pscore to float64 there).  One workgroup per stream,
+// 3125 candidates; ties resolve to the lowest index like np.argmax.  Removes the device->host
+// round trip between track_mask and track_refine.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+    const int b = blockIdx.x, SS = p.S * p.S, n = p.A * SS;
+    const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
+    const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
+    const double tw = p.target_wh[2 * b], th = p.target_wh[2 * b + 1];
+    const double tpad = (tw + th) * 0.5;
+    const double tsz = sqrt((tw + tpad) * (th + tpad));
+    const double tratio = tw / th;
+    const int ori = -(p.S / 2) * p.stride;
+    double best = -1e300;
+    int best_i = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int a = i / SS, rem = i - a * SS;
+        const double c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
+        const double score = 1.0 / (1.0 + exp(c0 - c1));          // softmax(...)[fg]
+        const double aw = p.anchor_w[a], ah = p.anchor_h[a];
+        const double w = exp((double)loc[(2 * p.A + a) * SS + rem]) * aw;
+        const double h = exp((double)loc[(3 * p.A + a) * SS + rem]) * ah;
+        const double pad = (w + h) * 0.5;
+        const double sz = sqrt((w + pad) * (h + pad));
+        double s_c = sz / tsz;  s_c = fmax(s_c, 1.0 / s_c);
+        double r_c = tratio / (w / h);  r_c = fmax(r_c, 1.0 / r_c);
+        const double penalty = exp(-(r_c * s_c - 1.0) * p.penalty_k);
+        const double ps = penalty * score * (1.0 - p.window_influence) + p.window[rem] * p.window_influence;
+        if (ps > best || (ps == best && i < best_i)) { best = ps; best_i = i; }
+    }
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const double v = sv[threadIdx.x + s];
+            const int j = si[threadIdx.x + s];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int i = si[0], a = i / SS, rem = i - a * SS, y = rem / p.S, x = rem - y * p.S;
+        if (p.pos_out) { p.pos_out[2 * b] = y; p.pos_out[2 * b + 1] = x; }
+        if (p.box_out) {
+            const double aw = p.anchor_w[a], ah = p.anchor_h[a];
+            const double c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
+            const double score = 1.0 / (1.0 + exp(c0 - c1));
+            const double cx = (double)loc[(0 * p.A + a) * SS + rem] * aw + (ori + p.stride * x);
+            const double cy = (double)loc[(1 * p.A + a) * SS + rem] * ah + (ori + p.stride * y);
+            const double w = exp((double)loc[(2 * p.A + a) * SS + rem]) * aw;
+            const double h = exp((double)loc[(3 * p.A + a) * SS + rem]) * ah;
+            const double pad = (w + h) * 0.5, sz = sqrt((w + pad) * (h + pad));
+            double s_c = sz / tsz;  s_c = fmax(s_c, 1.0 / s_c);
+            double r_c = tratio / (w / h);  r_c = fmax(r_c, 1.0 / r_c);
+            const double penalty = exp(-(r_c * s_c - 1.0) * p.penalty_k);
+            float *o = p.box_out + 8 * b;
+            o[0] = (float)cx; o[1] = (float)cy; o[2] = (float)w; o[3] = (float)h;
+            o[4] = (float)score; o[5] = (float)penalty; o[6] = (float)sv[0]; o[7] = (float)i;
+        }
+    }
+}
+
+int launch_decode(const DecodeParams &p, void *stream) {
+    if (p.A > 8 || p.B < 1) return -1;
+    hipLaunchKernelGGL(decode_kernel, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 }  // namespace smk

@@ -125,6 +125,19 @@ struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
 struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; };  // NCHW f32 -> NHWC dtype
 struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; };  // NHWC dtype -> NCHW f32
 
+// on-device restatement of the host decode of tools/test.py:205-254 (one workgroup per stream)
+struct DecodeParams {
+    const float *cls;        // [B][2*A][S][S] f32 NCHW
+    const float *loc;        // [B][4*A][S][S]
+    const float *target_wh;  // [B][2] target size in crop pixels (w, h) = target_sz * scale_x
+    const double *window;    // [S*S] cosine window (outer(hanning, hanning))
+    int *pos_out;            // [B][2] (y, x) of the best anchor position
+    float *box_out;          // [B][8] cx, cy, w, h (crop pixels), score, penalty, pscore, best_id
+    int B, A, S, stride;
+    float anchor_w[8], anchor_h[8];
+    double penalty_k, window_influence;
+};
+
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 struct TileChoice { int bm, bn; };
 TileChoice choose_tile(const ConvParams &p, int dtype);
@@ -134,6 +147,7 @@ int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
+int launch_decode(const DecodeParams &p, void *stream);
 const void *zero_page();   // device-resident 8 KB of zeros (allocated on first use, per device)
 
 }  // namespace smk

@@ -97,6 +97,8 @@ class Custom(nn.Module):
         self._weights_dirty = True
         self._io = {}
         self._tracked = 0
+        self._hp = None
+        self._hp_dirty = True
         self.zf = None          # reference attribute (custom.py:174); opaque handle here
 
     # -- weights --------------------------------------------------------------------------
@@ -128,6 +130,7 @@ class Custom(nn.Module):
             self._ctx, self._ctx_device = ctx, dev
             _lib.check(L.smk_set_graph_mode(ctx, 1 if self._graph else 0))
             self._weights_dirty = True
+            self._hp_dirty = True
             self._io = {}
         if self._weights_dirty:
             for name, t in self.state_dict().items():
@@ -217,6 +220,81 @@ class Custom(nn.Module):
         cls, loc, _ = self._track(search, _lib.TRACK_BOX, False)
         self._tracked = 0
         return cls, loc
+
+    # -- additive API: on-device decode + fused per-frame step -------------------
+    def set_tracker_hp(self, penalty_k=0.04, window_influence=0.4):
+        """hp of the host decode (config_*.json 'hp'); anchors come from self.anchors
+        (utils/anchors.py:40-50: integer-truncated ws/hs times scale)."""
+        import math
+        self._hp = (float(penalty_k), float(window_influence))
+        wh = []
+        size = self.anchors["stride"] ** 2
+        for r in self.anchors["ratios"]:
+            ws = int(math.sqrt(size * 1.0 / r))
+            hs = int(ws * r)
+            for sc in self.anchors["scales"]:
+                wh += [ws * sc, hs * sc]
+        self._anchor_wh = np.asarray(wh, dtype=np.float32)
+        self._hp_dirty = True
+
+    def _push_hp(self):
+        if getattr(self, "_hp", None) is None:
+            self.set_tracker_hp()
+        if self._hp_dirty:
+            _lib.check(_lib.lib().smk_set_decode_params(
+                self._ctx, self._anchor_wh.ctypes.data_as(ctypes.c_void_p), 5, int(self.anchors["stride"]),
+                self._hp[0], self._hp[1]))
+            self._hp_dirty = False
+
+    def decode(self, cls, loc, target_wh):
+        """Device restatement of tools/test.py:205-254 for B streams.
+        target_wh: [B,2] float32 CUDA tensor, target size in crop pixels (w,h) = target_sz*scale_x.
+        -> (pos [B,2] int32 (y,x), box [B,8] float32: cx,cy,w,h,score,penalty,pscore,best_id)."""
+        B = cls.shape[0]
+        self._ensure(cls, B)
+        self._push_hp()
+        dev = cls.device
+        with torch.cuda.device(self._ctx_device):
+            pos = torch.empty((B, 2), dtype=torch.int32, device=dev)
+            box = torch.empty((B, 8), dtype=torch.float32, device=dev)
+            twh = target_wh.to(dev, torch.float32).contiguous()
+            _lib.check(_lib.lib().smk_decode(self._ctx, cls.contiguous().data_ptr(), loc.contiguous().data_ptr(), B,
+                                            twh.data_ptr(), pos.data_ptr(), box.data_ptr(), _lib.current_stream_ptr()))
+        return pos, box
+
+    def track_step(self, search, target_wh, refine=None, mask_head=True):
+        """One frame for B streams without leaving the device: track(_mask) -> decode -> refine at
+        the decoded positions, replayed as ONE captured graph.
+        -> dict(cls, loc, mask, box [B,8], refine [B,16129] or None).  With graph replay the
+        returned tensors are views of persistent I/O buffers (valid until the next call)."""
+        if self.zf is None:
+            raise RuntimeError("template() must be called before track_step()")
+        B = search.shape[0]
+        self._ensure(search, B)
+        self._push_hp()
+        if refine is None:
+            refine = self.variant == "sharp"
+        flags = _lib.TRACK_BOX if self.variant == "rpn" else _lib.TRACK_MASK
+        want_mask = self.variant != "rpn" and mask_head
+        if self.variant != "rpn" and not mask_head:
+            flags |= _lib.TRACK_NO_MASK_HEAD
+        dev = search.device
+        S, A = spec.SCORE_SIZE, self.anchor_num
+        with torch.cuda.device(self._ctx_device):
+            x = self._stage_in("x", search, spec.SEARCH_SIZE)
+            twh = self._buf("twh", (B, 2), dev)
+            twh.copy_(target_wh)
+            cls = self._out("cls", (B, 2 * A, S, S), dev)
+            loc = self._out("loc", (B, 4 * A, S, S), dev)
+            mask = self._out("mask", (B, spec.MASK_OUT ** 2, S, S), dev) if want_mask else None
+            box = self._out("box", (B, 8), dev)
+            ref = self._out("refine", (B, spec.REFINE_OUT ** 2), dev) if refine else None
+            _lib.check(_lib.lib().smk_step(
+                self._ctx, x.data_ptr(), B, flags, twh.data_ptr(), cls.data_ptr(), loc.data_ptr(),
+                mask.data_ptr() if mask is not None else None, box.data_ptr(),
+                ref.data_ptr() if ref is not None else None, _lib.current_stream_ptr()))
+        self._tracked = B if self.variant != "rpn" else 0
+        return {"cls": cls, "loc": loc, "mask": mask, "box": box, "refine": ref}
 
     # -- per-launch profiling (HIP events around every kernel; bypasses graph replay) -----------
     def profile(self, enable=True):

@@ -150,3 +150,46 @@ def test_lazy_mask_head_matches():
     assert mask is None
     assert rel_err(cls.cpu().numpy(), g["cls"]) <= 1e-4
     assert rel_err(m.track_refine(g["best_yx"]).cpu().numpy(), g["refine"]) <= 1e-4
+
+
+def test_device_decode_matches_host_decode():
+    """smk_decode vs the oracle's restatement of tools/test.py:205-254: argmax index bit-exact,
+    box values within 1e-5 (float64 on both sides, float32 storage)."""
+    from siammask_amd.custom import build
+    g = load_golden("sharp_damped_b2")
+    m = _model("sharp", "synthetic_damped", "f32", False)
+    m.set_tracker_hp(0.04, 0.4)
+    cls = torch.from_numpy(g["cls"]).cuda()
+    loc = torch.from_numpy(g["loc"]).cuda()
+    for twh in ((60.0, 80.0), (33.0, 121.5)):
+        t = torch.tensor([twh, twh], dtype=torch.float32).cuda()
+        pos, box = m.decode(cls, loc, t)
+        pos, box = pos.cpu().numpy(), box.cpu().numpy()
+        for b in range(2):
+            bid, dy, dx, _ = decode_best(g["cls"][b], g["loc"][b], target_sz=twh)
+            assert int(box[b, 7]) == bid and tuple(pos[b]) == (dy, dx)
+            want = decode_best.last["box"]
+            assert np.abs(box[b, :7] - want[:7]).max() <= 1e-5 * np.abs(want[:7]).max()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_fused_step_equals_separate_calls(dtype):
+    """track_step (track -> device decode -> refine, one graph, fork/join concurrency) gives the
+    same tensors as track_mask + host decode + track_refine."""
+    g = load_golden("sharp_damped_b2")
+    z = torch.from_numpy(g["z_u8"].astype(np.float32)).cuda()
+    x = torch.from_numpy(g["x_u8"].astype(np.float32)).cuda()
+    m = _model("sharp", "synthetic_damped", dtype, True)
+    m.template(z)
+    cls, loc, mask = m.track_mask(x)
+    cls, loc, mask = cls.clone(), loc.clone(), mask.clone()
+    best = [decode_best(cls[b].cpu().numpy(), loc[b].cpu().numpy()) for b in range(2)]
+    ref = m.track_refine(np.array([[t[1], t[2]] for t in best])).clone()
+    twh = torch.tensor([[60.0, 80.0]] * 2).cuda()
+    out = m.track_step(x, twh)
+    torch.cuda.synchronize()
+    assert torch.equal(out["cls"], cls) and torch.equal(out["loc"], loc) and torch.equal(out["mask"], mask)
+    assert [int(v) for v in out["box"][:, 7].cpu()] == [t[0] for t in best]
+    assert torch.equal(out["refine"], ref)
+    if dtype == "f32":
+        assert rel_err(out["refine"].cpu().numpy(), g["refine"]) <= 1e-4
