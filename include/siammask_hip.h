@@ -128,7 +128,7 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const float
 int smk_set_graph_mode(smk_ctx *ctx, int enable);
 
 /* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured
- * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16", "stages" 0|2|3, "concurrency" 0|1
+ * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16", "stages" 0|2|3|4, "kt" 0|128|256 (K-tile bytes), "concurrency" 0|1
  * (the latter applies to contexts created afterwards). */
 int smk_tune(const char *key, int value);
 
@@ -170,7 +170,9 @@ typedef struct smk_conv_geom {
 
 /* algo: low byte 0 = MFMA kernel, NHWC epilogue; 1 = naive kernel, NHWC epilogue;
  *                2 = MFMA kernel, NCHW-f32 epilogue; 3 = naive kernel, NCHW-f32 epilogue;
- *       second byte: tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64.
+ *       second byte: bits 0-3 tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64;
+ *                    bits 4-5 K tile 0 auto, 1 = 128 B, 2 = 256 B; bits 6-7 LDS ring depth
+ *                    0 auto, 1..3 = 2..4 stages.
  * w_host [Cout,cin_len,k,k], b_host [Cout] or NULL (host); x_dev, res_dev [B,Cout,Ho,Wo],
  * y_dev (device); pos_host: B (y,x) pairs or NULL.  Synchronises the stream (test helper). */
 int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x_dev,
@@ -184,6 +186,12 @@ int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, in
                     int H, int W, int kh, int kw, float *y_dev, void *stream);
 int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W,
                         float *y_dev, void *stream);
+
+/* measurement aid: time `iters` back-to-back launches of the MFMA conv kernel for geometry g
+ * (random f16/f32 operands allocated internally, NHWC epilogue unless algo low byte is 2) with
+ * HIP events on `stream`; *usec_out = average microseconds per launch.  algo as above. */
+int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, int iters,
+                   float *usec_out, void *stream);
 
 /* host-only (no GPU): y = epilogue(conv(x, w) + b) computed on the HOST by walking the packed
  * weight matrix with the device kernels' own row/tap decode + gather-offset functions.

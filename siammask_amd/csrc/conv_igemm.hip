@@ -62,11 +62,6 @@ template <> struct Traits<_Float16> {
     }
 };
 
-// byte offset of (row, 16-byte slot) inside a [rows][128 B] LDS tile, XOR swizzled
-__device__ __forceinline__ int lds_off(int row, int slot) {
-    return row * KTILE_BYTES + ((slot ^ ((row >> 1) & 7)) << 4);
-}
-
 template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -81,24 +76,61 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned char *lds_base
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// wait until at most n_tiles * NP of this wave's LDS-DMA pieces are still in flight
+template <int NP> __device__ __forceinline__ void wait_tiles(int n_tiles) {
+    if (n_tiles <= 0) wait_vmcnt<0>();
+    else if (n_tiles == 1) wait_vmcnt<NP>();
+    else wait_vmcnt<2 * NP>();
+}
 
-template <typename T, int BM, int BN, int OUT_MODE, int NSTAGE>
+// XOR swizzle of the 16-byte slot inside an LDS row (SPR slots per row): makes the ds_read_b128
+// fragment reads (32 consecutive rows, same logical slot) bank-conflict free.
+//   SPR = 8  (128-byte rows, two rows per 256-byte bank line): (row>>1)&7
+//   SPR = 16 (256-byte rows, one row per bank line):            row&15
+template <int SPR> __device__ __forceinline__ int swz(int row) {
+    return SPR == 8 ? ((row >> 1) & 7) : (row & 15);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_igemm_kernel<T, WM, WN, WK, KT, OUT_MODE, NSTAGE>
+//   256 threads = 4 waves arranged WM x WN x WK (WM*WN*WK == 4).  EVERY wave owns a 64x64
+//   accumulator tile (2x2 MFMA 32x32 fragments): the LDS->register traffic per MFMA is the
+//   same for all workgroup shapes (4 ds_read_b128 per 4 MFMAs).  Workgroup tile = 64*WM x 64*WN;
+//   when WK > 1 the waves of a K-group split the k-steps of every K tile between them and the
+//   partial sums are added in the epilogue (through LDS), so small tiles stay LDS-efficient.
+//   K tile = KT bytes of K per row (128 or 256), staged by LDS-DMA into an NSTAGE-deep ring.
+//
+//   Software pipeline (per wave, per K tile): the fragments of k-step s+1 are read from LDS
+//   while the MFMAs of step s run (register double buffer), the LDS-DMA pieces of tile
+//   kt+NSTAGE-1 are issued a few at a time between the MFMA groups, and the single barrier per
+//   K tile sits behind the last MFMA group of the tile, so that it is covered by matrix-pipe
+//   time instead of exposing it.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(WM * WN * WK == 4, "four waves per workgroup");
     typedef Traits<T> TR;
+    typedef typename TR::frag_t frag_t;
     constexpr int VE = TR::VE;
-    constexpr int BK = KTILE_BYTES / (int)sizeof(T);
-    constexpr int FM = BM / 64, FN = BN / 64;     // 32x32 fragments per wave
-    constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte LDS-DMA pieces per thread per K tile
-    constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
-    constexpr int LDE = (OUT_MODE == OUT_NCHW_F32) ? WTN + 1 : WTN + 4;
-    constexpr int STAGE_BYTES = (BM + BN) * KTILE_BYTES;
-    constexpr int EPI_BYTES = 4 * WTM * LDE * 4;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BK = KT / (int)sizeof(T);
+    constexpr int SPR = KT / 16;               // 16-byte slots per LDS row
+    constexpr int RPR = 256 / SPR;             // rows filled by one round of 256 LDS-DMA pieces
+    constexpr int RA = BM / RPR, RB = BN / RPR, NP = RA + RB;   // pieces per thread per K tile
+    constexpr int NKS = (KT / 32) / WK;        // k-steps (32 bytes of K) per K tile per wave
+    static_assert(NKS >= 2 && NKS % 2 == 0, "register double buffer needs an even step count");
+    constexpr int AHEAD = NSTAGE - 1;          // K tiles in flight
+    static_assert(AHEAD >= 1 && AHEAD <= 3, "ring depth 2..4");
+    constexpr int STAGE_BYTES = (BM + BN) * KT;
+    constexpr int EROWS = OUT_MODE == OUT_NCHW_F32 ? 64 : 32;   // accumulator rows per epilogue pass
+    constexpr int LDE = OUT_MODE == OUT_NCHW_F32 ? 65 : 68;
+    constexpr int EPI_BYTES = 4 * EROWS * LDE * 4;
     constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int g = blockIdx.z;
     const int cin_off = p.cin_off + g * p.g_cin_off;
     const T *wgt = (const T *)p.wgt + (size_t)g * p.g_wgt_off * p.Kpad;
@@ -125,177 +157,277 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // LDS-DMA writes lane-linear: lane l of wave w fills (row 8w + l/8 [+32i], physical slot l%8).
+    // LDS-DMA writes lane-linear: thread `tid` fills (row tid/SPR [+RPR*i], physical slot tid%SPR).
     // The XOR swizzle therefore goes on the SOURCE: this thread fetches the logical 16-byte
-    // slot  phys ^ ((row>>1)&7)  of its row, and the fragment reads apply the same XOR.
-    const int lrow = tid >> 3;
-    const int slot = (tid & 7) ^ ((lrow >> 1) & 7);
+    // slot  phys ^ swz(row)  of its row, and the fragment reads apply the same XOR.
+    const int lrow = tid / SPR;
+    const int slot = (tid % SPR) ^ swz<SPR>(lrow);      // swz(lrow + RPR*i) == swz(lrow)
 
     // ---- per-thread row bookkeeping for the A gather --------------------------------------
     RowInfo ri[RA];
     bool rvalid[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = m0 + lrow + 32 * i;
+        int m = m0 + lrow + RPR * i;
         rvalid[i] = m < p.M;
         ri[i] = row_info(p, rvalid[i] ? m : 0, p.pos);
     }
     const char *in = (const char *)p.in;
-    const long zero_off = (const char *)p.zero - in;   // 8 KB of zeros: source of all padding
+    const long zero_off = (const char *)p.zero - in;   // 16 KB of zeros: source of all padding
     const char *wsrc[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-        wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + 32 * i) * p.Kpad + slot * VE);
+        wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + RPR * i) * p.Kpad + slot * VE);
     const int nk = (p.K + BK - 1) / BK;
 
     // This thread always fetches the same 16-byte slot of every K tile, i.e. K index
-    // kt*BK + slot*VE.  Its (tap, channel) position advances incrementally; the per-row source
-    // offsets are recomputed only when the tap changes (once per Ci/BK tiles on the heavy
-    // layers), which keeps the address VALU work out of the MFMA loop.  Padding (conv zero
-    // padding, rows >= M, K tail) reads the zero page, so the loads are branch-free.
-    KDecode kd = decode_k(slot * VE, p.Ci, p.kw);
+    // kt*BK + slot*VE.  Its (tap, channel) position is decoded per tile with a shift (Ci is a
+    // power of two on this path; p.ci_shift < 0 selects the division fallback).  When a K tile
+    // never straddles a tap (Ci >= BK) the tap is wave-uniform and the per-row source offsets
+    // are recomputed only when it changes (scalar branch); otherwise they are recomputed per
+    // tile.  Padding (conv zero padding, rows >= M, K tail) reads the zero page, so the loads are
+    // branch-free.
+    const bool tap_uniform = p.ci_shift >= 0 && p.Ci >= BK;
+    int cur_tap_s = -1;                                // wave-uniform tap of the last decode
+    int cur_c = 0;
     long a_off[RA];                                    // byte offsets relative to `in`
-    auto tap_offsets = [&]() {
+    auto tap_offsets = [&](int tap) {
+        const int kh_i = (tap * p.kw_magic) >> 16;
+        const int kw_i = tap - kh_i * p.kw;
+        const bool tap_ok = kh_i < p.kh;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            long off = -1;
-            if (rvalid[i] && kd.kh_i < p.kh) {
-                KDecode d0 = kd;
-                d0.c = 0;
-                off = gather_offset(p, ri[i], d0, cin_off);
+            const int ly = ri[i].ly0 + kh_i * p.dil, lx = ri[i].lx0 + kw_i * p.dil;
+            bool ok = rvalid[i] & tap_ok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
+            int sy, sx;
+            if (p.ups) {                               // nearest upsampling (uniform branch)
+                sy = (ly * p.Hs) / p.Hl;
+                sx = (lx * p.Ws) / p.Wl;
+            } else {
+                sy = ly + ri[i].oy_org;
+                sx = lx + ri[i].ox_org;
             }
-            a_off[i] = off >= 0 ? off * (long)sizeof(T) : zero_off;
+            ok = ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
+            const long off = (((long)(ri[i].b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off) * (long)sizeof(T);
+            a_off[i] = ok ? off : zero_off;
         }
     };
-    tap_offsets();
-    auto advance = [&]() {
-        kd.c += BK;
-        if (kd.c >= p.Ci) {
-            do {
-                kd.c -= p.Ci;
-                if (++kd.kw_i == p.kw) { kd.kw_i = 0; ++kd.kh_i; }
-            } while (kd.c >= p.Ci);
-            tap_offsets();
+    auto set_tile = [&](int kt) {
+        if (tap_uniform) {
+            const int k0 = kt * BK;
+            const int tap = k0 >> p.ci_shift;
+            cur_c = (k0 & (p.Ci - 1)) + slot * VE;
+            if (tap != cur_tap_s) {
+                cur_tap_s = tap;
+                tap_offsets(tap);
+            }
+        } else {
+            const int k = kt * BK + slot * VE;
+            int tap;
+            if (p.ci_shift >= 0) { tap = k >> p.ci_shift; cur_c = k & (p.Ci - 1); }
+            else { tap = k / p.Ci; cur_c = k - tap * p.Ci; }
+            tap_offsets(tap);
         }
     };
-    // issue the LDS-DMA of K tile kt into ring slot `buf` (RA + RB loads per thread)
-    auto issue = [&](int kt, int buf) {
-        unsigned char *sA = smem + buf * STAGE_BYTES + wave * (8 * KTILE_BYTES);
-        unsigned char *sB = sA + BM * KTILE_BYTES;
-        const long cb = (long)kd.c * (long)sizeof(T);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) glds16(in + a_off[i] + cb, sA + i * (32 * KTILE_BYTES));
-        const long kb = (long)kt * KTILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) glds16(wsrc[i] + kb, sB + i * (32 * KTILE_BYTES));
+    // LDS-DMA piece j (0..NP-1) of K tile kt into ring slot `buf`
+    auto issue_piece = [&](int j, int kt, int buf) {
+        unsigned char *sA = smem + buf * STAGE_BYTES + wave * 1024;
+        if (j < RA) {
+            glds16(in + a_off[j] + (long)cur_c * (long)sizeof(T), sA + j * 4096);
+        } else {
+            glds16(wsrc[j - RA] + (long)kt * KT, sA + BM * KT + (j - RA) * 4096);
+        }
     };
 
-    floatx16 acc[FM][FN];
+    floatx16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- prologue: NSTAGE-1 tiles in flight --------------------------------------------------
-    issue(0, 0);
-    if (NSTAGE == 3 && nk > 1) { advance(); issue(1, 1); }
-
+    // ---- fragment addressing ------------------------------------------------------------------
     const int frow = lane & 31, fhalf = lane >> 5;
+    const int fsw = swz<SPR>(frow);                    // swz(64*w + 32*i + frow) == swz(frow)
+    const int a_row_off = (wm * 64 + frow) * KT;
+    const int b_row_off = BM * KT + (wn * 64 + frow) * KT;
+    frag_t fa[2][2], fb[2][2];                         // [step parity][fragment]
+    auto read_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
+        const unsigned char *sb = smem + buf * STAGE_BYTES;
+        const int so = (((s * WK + wk) * 2 + fhalf) ^ fsw) << 4;
+        a[0] = *(const frag_t *)(sb + a_row_off + so);
+        a[1] = *(const frag_t *)(sb + a_row_off + 32 * KT + so);
+        b[0] = *(const frag_t *)(sb + b_row_off + so);
+        b[1] = *(const frag_t *)(sb + b_row_off + 32 * KT + so);
+    };
+    // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
+    auto mma_part = [&](int par, int q0, int q1) {
+#pragma unroll
+        for (int q = q0; q < q1; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+    };
+
+    // ---- prologue: up to AHEAD tiles in flight, tile 0 landed, its first fragments in registers
+#pragma unroll
+    for (int tt = 0; tt < AHEAD; ++tt)
+        if (tt < nk) {
+            set_tile(tt);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) issue_piece(j, tt, tt);
+        }
+    wait_tiles<NP>((nk < AHEAD ? nk : AHEAD) - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, fa[0], fb[0]);
+
+    // The LDS-DMA pieces of a tile are spread over the first PS k-steps of the iteration that
+    // issues it; the last k-step carries the hand-over to the next tile instead.
+    constexpr int PS = NKS - 1;
     int cur = 0;                       // ring slot holding tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        // my pieces of tile kt have landed (tiles issued after it may still be in flight) ...
-        if (NSTAGE == 3 && kt + 1 < nk) wait_vmcnt<RA + RB>();
-        else wait_vmcnt<0>();
-        // ... and so have everybody else's; all waves are also done reading the slot refilled below
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int ahead = NSTAGE - 1;
-        if (kt + ahead < nk) {
-            int nxt = cur + ahead;
-            if (nxt >= NSTAGE) nxt -= NSTAGE;
-            advance();
-            issue(kt + ahead, nxt);
+    int kt = 0;
+    // Issue order inside a k-step (pinned with sched_barrier; hipcc waits lgkmcnt(0) for LDS data,
+    // so a read must be old by the time the next wait comes):
+    //   MFMA 0 of step s                      <- waits for the fragments read one step ago
+    //   ds_read fragments of step s+1, LDS-DMA pieces of tile kt+AHEAD
+    //   MFMA 1..3 of step s                   <- ~100 cycles of matrix pipe cover the reads
+    // The last k-step of a tile carries the hand-over instead: MFMA 0,1 | wait for tile kt+1,
+    // barrier, read its first fragments | MFMA 2,3.
+    // ---- steady state: tile kt+AHEAD exists, so every iteration issues NP pieces ------------
+    for (; kt + AHEAD < nk; ++kt) {
+        int islot = cur + AHEAD;
+        if (islot >= NSTAGE) islot -= NSTAGE;
+        int nxt = cur + 1;
+        if (nxt == NSTAGE) nxt = 0;
+        set_tile(kt + AHEAD);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            if (s + 1 < NKS) {
+                mma_part(s & 1, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+                for (int j = (s * NP) / PS; j < ((s + 1) * NP) / PS; ++j) issue_piece(j, kt + AHEAD, islot);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(s & 1, 1, 4);
+            } else {
+                mma_part(s & 1, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                // hand-over: my pieces of tile kt+1 have landed (AHEAD-1 younger tiles may still be
+                // in flight), all my LDS reads of tile kt are complete ...
+                wait_vmcnt<(AHEAD - 1) * NP>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // ... and so for every other wave: tile kt+1 is readable, the slot of tile kt is free
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                read_frags(nxt, 0, fa[0], fb[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(s & 1, 2, 4);
+            }
         }
-        const unsigned char *sA = smem + cur * STAGE_BYTES;
-        const unsigned char *sB = sA + BM * KTILE_BYTES;
+        cur = nxt;
+    }
+    // ---- drain: nothing left to issue --------------------------------------------------------
+    for (; kt < nk; ++kt) {
+        int nxt = cur + 1;
+        if (nxt == NSTAGE) nxt = 0;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            typename TR::frag_t a[FM], b[FN];
-            const int sl = ks * 2 + fhalf;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-                a[i] = *(const typename TR::frag_t *)(sA + lds_off(wm * WTM + i * 32 + frow, sl));
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-                b[j] = *(const typename TR::frag_t *)(sB + lds_off(wn * WTN + j * 32 + frow, sl));
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) TR::mma(acc[i][j], a[i], b[j]);
+        for (int s = 0; s < NKS; ++s) {
+            if (s + 1 < NKS) {
+                mma_part(s & 1, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(s & 1, 1, 4);
+            } else {
+                mma_part(s & 1, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 1 < nk) {
+                    wait_tiles<NP>(nk - 2 - kt);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    read_frags(nxt, 0, fa[0], fb[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_part(s & 1, 2, 4);
+            }
         }
-        if (++cur == NSTAGE) cur = 0;
+        cur = nxt;
     }
     __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (per-wave region) -> fused bias/res/relu -> global ---
-    float *e = (float *)smem + wave * (WTM * LDE);
+    // ---- epilogue: accumulators -> LDS (per-wave region) -> sum over the K-group -> fused
+    //      bias/res/relu -> global.  EROWS accumulator rows per pass.
+    float *e = (float *)smem + wave * (EROWS * LDE);
+    const float *eg = (const float *)smem + (wave - wk) * (EROWS * LDE);   // first wave of my K-group
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int ep = 0; ep < 64 / EROWS; ++ep) {
+        if (ep > 0) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int ii = 0; ii < EROWS / 32; ++ii)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                int col = j * 32 + frow;
-                e[row * LDE + col] = acc[i][j][r];
-            }
-    __syncthreads();
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = ep * (EROWS / 32) + ii;
+                    int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    int col = j * 32 + frow;
+                    e[row * LDE + col] = acc[i][j][r];
+                }
+        __syncthreads();
 
-    if (OUT_MODE == OUT_NHWC) {
-        constexpr int LPR = WTN / 4;      // lanes per output row (4 channels each)
-        constexpr int RPP = 64 / LPR;     // rows per pass
-        const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
-        const int n = n0 + wn * WTN + c4;
-        if (n < p.Nst) {
-            const floatx4 bv = *(const floatx4 *)(bias + n);
-            T *out = (T *)p.out;
-            const T *res = (const T *)p.res;
-#pragma unroll 4
-            for (int pass = 0; pass < WTM / RPP; ++pass) {
-                const int row = pass * RPP + r0;
-                const int m = m0 + wm * WTM + row;
-                if (m < p.M) {
-                    floatx4 v = *(const floatx4 *)(e + row * LDE + c4);
-                    v += bv;
-                    floatx4 rv = {0.f, 0.f, 0.f, 0.f};
-                    if (p.res_mode != RES_NONE)
-                        rv = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n);
-                    if (p.res_mode == RES_PRE_RELU) v += rv;
-                    if (p.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        if (OUT_MODE == OUT_NHWC) {
+            // 16 lanes x 4 channels per row, 4 rows per pass; the WK waves of a K-group share the rows
+            constexpr int RW = EROWS / WK;        // rows handled by this wave
+            const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+            const int n = n0 + wn * 64 + c4;
+            if (n < p.Nst) {
+                const floatx4 bv = *(const floatx4 *)(bias + n);
+                T *out = (T *)p.out;
+                const T *res = (const T *)p.res;
+#pragma unroll
+                for (int pass = 0; pass < RW / 4; ++pass) {
+                    const int row = wk * RW + pass * 4 + r0;
+                    const int m = m0 + wm * 64 + ep * EROWS + row;
+                    if (m < p.M) {
+                        floatx4 v = *(const floatx4 *)(eg + row * LDE + c4);
+#pragma unroll
+                        for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(eg + q * (EROWS * LDE) + row * LDE + c4);
+                        v += bv;
+                        floatx4 rv = {0.f, 0.f, 0.f, 0.f};
+                        if (p.res_mode != RES_NONE)
+                            rv = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n);
+                        if (p.res_mode == RES_PRE_RELU) v += rv;
+                        if (p.relu) {
+                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        }
+                        if (p.res_mode == RES_POST_RELU) v += rv;
+                        TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
                     }
-                    if (p.res_mode == RES_POST_RELU) v += rv;
-                    TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
                 }
             }
-        }
-    } else {
-        constexpr int CG = 64 / WTM;      // column groups processed concurrently
-        const int row = lane % WTM, cg = lane / WTM;
-        const int m = m0 + wm * WTM + row;
-        if (m < p.M) {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, pos = m - b * hw;
-            float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
-            for (int j = cg; j < WTN; j += CG) {
-                const int n = n0 + wn * WTN + j;
-                if (n < p.N) {
-                    float v = e[row * LDE + j] + bias[n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    obase[(size_t)n * hw] = v;
+        } else {
+            // NCHW f32: lanes run along m (contiguous positions of one channel plane)
+            const int row = lane;                              // EROWS == 64
+            const int m = m0 + wm * 64 + row;
+            if (m < p.M) {
+                const int hw = p.Ho * p.Wo;
+                const int b = m / hw, pos = m - b * hw;
+                float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
+                constexpr int CW = 64 / WK;                    // columns handled by this wave
+#pragma unroll 4
+                for (int jj = 0; jj < CW; ++jj) {
+                    const int j = wk * CW + jj;
+                    const int n = n0 + wn * 64 + j;
+                    if (n < p.N) {
+                        float v = eg[row * LDE + j];
+#pragma unroll
+                        for (int q = 1; q < WK; ++q) v += eg[q * (EROWS * LDE) + row * LDE + j];
+                        v += bias[n];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        obase[(size_t)n * hw] = v;
+                    }
                 }
             }
         }
@@ -357,45 +489,76 @@ __global__ void conv_naive_kernel(const ConvParams p) {
 static int g_num_cu = 256;
 Tuning g_tune;
 
+// Tile configurations: (BM, BN) in {128,64}^2, K tile 128 or 256 bytes, ring depth 2..4.
+// 64x64 tiles split K four ways inside the workgroup and therefore need the 256-byte K tile
+// (two k-steps per wave per tile).
+static int default_kt(int bm, int bn) { return (bm == 64 && bn == 64) ? 256 : 128; }
+static int default_stages(int bm, int bn, int kt) {
+    const int stage_bytes = (bm + bn) * kt;
+    if (stage_bytes >= 48 * 1024) return 2;
+    return 3;
+}
+
 TileChoice choose_tile(const ConvParams &p, int dtype) {
     (void)dtype;
+    TileChoice t;
     if (g_tune.force_tile) {
         static const int tb[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
-        TileChoice f{tb[g_tune.force_tile][0], tb[g_tune.force_tile][1]};
-        if (p.Nst <= 64) f.bn = 64;
-        return f;
+        t.bm = tb[g_tune.force_tile][0];
+        t.bn = tb[g_tune.force_tile][1];
+    } else {
+        auto blocks = [&](int bm, int bn) {
+            return (long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * (p.groups > 0 ? p.groups : 1);
+        };
+        t.bn = p.Nst > 64 ? 128 : 64;
+        t.bm = p.M > 64 ? 128 : 64;
+        // keep every CU busy: shrink the tile while the grid is smaller than the chip
+        const long want = (long)g_num_cu * g_tune.min_blocks_x16 / 16;
+        if (blocks(t.bm, t.bn) < want && t.bm == 128) t.bm = 64;
+        if (blocks(t.bm, t.bn) < want && t.bn == 128) t.bn = 64;
     }
-    auto blocks = [&](int bm, int bn) {
-        return (long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * (p.groups > 0 ? p.groups : 1);
-    };
-    TileChoice t;
-    t.bn = p.Nst > 64 ? 128 : 64;
-    t.bm = p.M > 64 ? 128 : 64;
-    // keep every CU busy: shrink the tile while the grid is smaller than the chip
-    const long want = (long)g_num_cu * g_tune.min_blocks_x16 / 16;
-    if (blocks(t.bm, t.bn) < want && t.bm == 128) t.bm = 64;
-    if (blocks(t.bm, t.bn) < want && t.bn == 128) t.bn = 64;
+    t.kt = g_tune.kt ? g_tune.kt : default_kt(t.bm, t.bn);
+    if (t.bm == 64 && t.bn == 64) t.kt = 256;
+    t.stages = g_tune.stages ? g_tune.stages : default_stages(t.bm, t.bn, t.kt);
     return t;
 }
 
-template <typename T, int BM, int BN, int OM>
-static int launch_one(const ConvParams &p, hipStream_t s) {
+template <typename T, int WM, int WN, int WK, int KT, int OM>
+static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Nst + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
-    // ring depth: 128x128 tiles run 2 stages (64 KB -> two workgroups per CU overlap each other),
-    // smaller tiles 3 stages (two K tiles in flight per workgroup); measured, see DESIGN.md
-    const int stages = g_tune.stages ? g_tune.stages : ((BM == 128 && BN == 128) ? 2 : 3);
-    if (stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, OM, 2>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, OM, 3>), grid, dim3(256), 0, s, p);
+    constexpr int STAGE_BYTES = (BM + BN) * KT;
+    constexpr int MAXST = 160 * 1024 / STAGE_BYTES;      // deepest ring that fits the 160 KB LDS
+    if (stages > MAXST) stages = MAXST;
+    if (stages > 4) stages = 4;
+    if (stages < 2) stages = 2;
+    if constexpr (MAXST >= 4) {
+        if (stages == 4) {
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(256), 0, s, p);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+    }
+    if constexpr (MAXST >= 3) {
+        if (stages == 3) {
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(256), 0, s, p);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <typename T, int OM>
 static int launch_tiles(const ConvParams &p, TileChoice t, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) return launch_one<T, 128, 128, OM>(p, s);
-    if (t.bm == 128 && t.bn == 64) return launch_one<T, 128, 64, OM>(p, s);
-    if (t.bm == 64 && t.bn == 128) return launch_one<T, 64, 128, OM>(p, s);
-    return launch_one<T, 64, 64, OM>(p, s);
+    const bool k256 = t.kt == 256;
+    if (t.bm == 128 && t.bn == 128)
+        return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(p, t.stages, s);
+    if (t.bm == 128 && t.bn == 64)
+        return k256 ? launch_stages<T, 2, 1, 2, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 1, 2, 128, OM>(p, t.stages, s);
+    if (t.bm == 64 && t.bn == 128)
+        return k256 ? launch_stages<T, 1, 2, 2, 256, OM>(p, t.stages, s) : launch_stages<T, 1, 2, 2, 128, OM>(p, t.stages, s);
+    return launch_stages<T, 1, 1, 4, 256, OM>(p, t.stages, s);
 }
 
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream) {

@@ -488,6 +488,10 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
             return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
     }
     p.xcd_mode = g_tune.xcd_mode;
+    p.ci_shift = -1;
+    for (int sh = 0; sh < 16; ++sh)
+        if ((1 << sh) == p.Ci) p.ci_shift = sh;
+    p.kw_magic = 65536 / p.kw + 1;                        // exact for tap < 4096 and kw <= 15
     p.zero = c->device >= 0 ? zero_page() : nullptr;      // device < 0: host-side walk (CPU tests)
     if (c->device >= 0 && !p.zero) return fail(SMK_E_HIP, "could not allocate the zero page");
     if (o.res) {
@@ -500,14 +504,21 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     return 0;
 }
 
+// code: bits 0-3 tile (0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64), bits 4-5 K tile
+// (0 auto, 1 128 B, 2 256 B), bits 6-7 ring depth (0 auto, 1..3 -> 2..4 stages)
 static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
-    switch (code) {
-        case 1: return TileChoice{128, 128};
-        case 2: return TileChoice{128, 64};
-        case 3: return TileChoice{64, 128};
-        case 4: return TileChoice{64, 64};
-        default: return choose_tile(p, dtype);
+    TileChoice t = choose_tile(p, dtype);
+    static const int tb[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const int tile = code & 15, kt = (code >> 4) & 3, st = (code >> 6) & 3;
+    if (tile >= 1 && tile <= 4) {
+        t.bm = tb[tile][0]; t.bn = tb[tile][1];
+        t.kt = (t.bm == 64 && t.bn == 64) ? 256 : 128;
+        t.stages = ((t.bm + t.bn) * t.kt >= 48 * 1024) ? 2 : 3;
     }
+    if (kt) t.kt = kt == 2 ? 256 : 128;
+    if (t.bm == 64 && t.bn == 64) t.kt = 256;
+    if (st) t.stages = st + 1;
+    return t;
 }
 
 static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, int B, const ConvOpt &o,
@@ -526,7 +537,7 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     const double out_bytes = (double)p.M * p.N * ng * (p.out_mode == OUT_NCHW_F32 ? 4 : es);
     const double bytes = in_bytes + out_bytes + (double)p.N * kreal * es * ng + (p.res ? (double)p.M * p.N * es : 0.0);
     char kn[64];
-    snprintf(kn, sizeof(kn), "conv_igemm<%s,%d,%d,%s>", dtname(c->dtype), t.bm, t.bn,
+    snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
     int rc;
     {
@@ -924,7 +935,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 4) return fail(SMK_E_ARG, "force_tile 0..4"); g_tune.force_tile = value; }
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
-    else if (!strcmp(key, "stages")) { if (value != 0 && value != 2 && value != 3) return fail(SMK_E_ARG, "stages 0|2|3"); g_tune.stages = value; }
+    else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
+    else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
     return 0;
 }
@@ -1213,6 +1225,78 @@ int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int 
     CvtOutParams co{y, y_dev, B, C, Ho, Wo, C, 0};
     if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
     HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// time repeated launches of one conv geometry (operands are pseudo-random, not zeros: DVFS hygiene)
+int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, int iters, float *usec_out,
+                   void *stream) {
+    if (!g || !usec_out || iters < 1) return fail(SMK_E_ARG, "smk_bench_conv: bad argument");
+    if (dtype != DT_F32 && dtype != DT_F16) return fail(SMK_E_ARG, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    PackedConv pc; Act in; ConvOpt o; int Ho, Wo;
+    CHK(fill_geom(g, pc, in, o, Ho, Wo));
+    const size_t es = esize(dtype);
+    TmpBufs tmp;
+    auto fill = [&](void **dst, size_t elems, float scale, unsigned seed) -> int {
+        CHK(tmp.alloc(dst, elems * es));
+        std::vector<unsigned char> h(elems * es);
+        unsigned st = seed * 2654435761u + 12345u;
+        for (size_t i = 0; i < elems; ++i) {
+            st = st * 1664525u + 1013904223u;
+            const float v = ((int)((st >> 9) & 0xffff) - 32768) * (scale / 32768.f);
+            if (dtype == DT_F16) ((_Float16 *)h.data())[i] = (_Float16)v; else ((float *)h.data())[i] = v;
+        }
+        HIPCHK(hipMemcpy(*dst, h.data(), elems * es, hipMemcpyHostToDevice));
+        return 0;
+    };
+    CHK(fill(&in.p, (size_t)g->B * g->H * g->W * in.C, 1.0f, 1));
+    CHK(fill(&pc.w, (size_t)pc.rows * pc.Kpad, 0.05f, 2));
+    CHK(tmp.alloc((void **)&pc.bias, (size_t)pc.rows * 4));
+    int *pos_dev = nullptr;
+    if (g->pos_mul) {
+        CHK(tmp.alloc((void **)&pos_dev, sizeof(int) * 2 * g->B));
+        std::vector<int> ph(2 * g->B);
+        for (int i = 0; i < 2 * g->B; ++i) ph[i] = 8 + (i * 5) % 9;
+        HIPCHK(hipMemcpy(pos_dev, ph.data(), ph.size() * 4, hipMemcpyHostToDevice));
+        o.pos = pos_dev;
+    }
+    const int mode = algo & 0xff;
+    o.tile_code = (algo >> 8) & 0xff;
+    Act out, res;
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8);
+    float *nchw = nullptr;
+    if (mode == 2) {
+        CHK(tmp.alloc((void **)&nchw, (size_t)g->B * g->Cout * Ho * Wo * 4));
+        o.nchw_out = nchw;
+    } else {
+        CHK(tmp.alloc(&out.p, (size_t)g->B * Ho * Wo * out.C * es));
+        if (with_res) {
+            res = out;
+            CHK(fill(&res.p, (size_t)g->B * Ho * Wo * out.C, 1.0f, 3));
+            o.res = &res; o.res_mode = RES_PRE_RELU;
+        }
+    }
+    smk_ctx fake;
+    fake.dtype = dtype;
+    HIPCHK(hipGetDevice(&fake.device));
+    ConvParams p;
+    CHK(conv_params(&fake, pc, in, mode == 2 ? nullptr : &out, g->B, o, p));
+    const TileChoice t = tile_from_code(o.tile_code, p, dtype);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i)
+        if (launch_conv_mfma(p, dtype, t, s)) return fail(SMK_E_HIP, "conv launch failed");
+    HIPCHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        if (launch_conv_mfma(p, dtype, t, s)) return fail(SMK_E_HIP, "conv launch failed");
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *usec_out = ms * 1000.f / iters;
     return 0;
 }
 

@@ -16,10 +16,9 @@ enum { DT_F32 = 0, DT_F16 = 1 };
 enum { RES_NONE = 0, RES_PRE_RELU = 1, RES_POST_RELU = 2 };
 enum { OUT_NHWC = 0, OUT_NCHW_F32 = 1 };
 
-// K-tile = 128 bytes of K per row for both dtypes (64 f16 / 32 f32 elements)
-constexpr int KTILE_BYTES = 128;
+// K tiles are 128 or 256 bytes of K per row (template parameter of the conv kernel)
 constexpr int NPAD_ALIGN = 128;   // weight rows padded to the largest N tile
-constexpr int KPAD_ALIGN = 64;    // elements; multiple of both K-tile sizes
+constexpr int KPAD_ALIGN = 128;   // elements; a multiple of every K-tile size (256 B of f16)
 
 struct ConvParams {
     const void *in;        // NHWC storage tensor [B][Hs][Ws][Cs] (dtype)
@@ -52,6 +51,8 @@ struct ConvParams {
     int g_wgt_off;         // rows of wgt/bias per group (multiple of NPAD_ALIGN)
     int g_cout_off;        // added to cout_off
     int xcd_mode;          // 0: tiles in launch order, 1: XCD-contiguous tm-major, 2: tn-major
+    int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
+    int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
 };
 
 // run-time tuning knobs (smk_tune): measured defaults, overridable for A/B runs
@@ -59,7 +60,8 @@ struct Tuning {
     int xcd_mode = 1;
     int force_tile = 0;        // 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64
     int min_blocks_x16 = 16;   // shrink tiles while grid < CUs * min_blocks_x16/16
-    int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2 or 3
+    int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2..4
+    int kt = 0;                // K tile bytes: 0 auto, 128 or 256
 };
 extern Tuning g_tune;
 
@@ -139,7 +141,7 @@ struct DecodeParams {
 };
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
-struct TileChoice { int bm, bn; };
+struct TileChoice { int bm, bn, kt, stages; };
 TileChoice choose_tile(const ConvParams &p, int dtype);
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
 int launch_conv_naive(const ConvParams &p, int dtype, void *stream);

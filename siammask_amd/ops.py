@@ -21,9 +21,14 @@ def _chk_cuda(*ts):
             raise RuntimeError("siammask_amd.ops run on the MI355X only (got a CPU tensor)")
 
 
+def tile_code(tile=None, kt=0, stages=0):
+    """second byte of `algo`: tile override, K-tile bytes (0|128|256), LDS ring depth (0|2|3|4)"""
+    return TILE[tile] | ({0: 0, 128: 1, 256: 2}[kt] << 4) | ({0: 0, 2: 1, 3: 2, 4: 3}[stages] << 6)
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=1, dtype="f32",
            algo="mfma", tile=None, win=None, ups=None, pos=None, pos_mul=0, pos_add=0, org=(0, 0),
-           cin_off=0, cin_len=0):
+           cin_off=0, cin_len=0, kt=0, stages=0):
     _chk_cuda(x, res)
     x = x.contiguous().float()
     B, Cin, H, W = x.shape
@@ -50,7 +55,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=
     y = torch.empty((B, g.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     p = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
     r = None if res is None else res.contiguous().float()
-    code = ALGO[algo] | (TILE[tile] << 8)
+    code = ALGO[algo] | (tile_code(tile, kt, stages) << 8)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().smk_op_conv2d_ex(
@@ -80,3 +85,20 @@ def maxpool3x3s2(x, dtype="f32"):
         _lib.check(_lib.lib().smk_op_maxpool3x3s2(_lib.DTYPE[dtype], x.data_ptr(), B, C, H, W, y.data_ptr(),
                                                   _lib.current_stream_ptr()))
     return y
+
+
+def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=None, kt=0, stages=0,
+               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50):
+    """average microseconds per launch of the MFMA conv kernel on this geometry (smk_bench_conv)"""
+    g = _lib.ConvGeom()
+    g.B, g.Cin, g.H, g.W = B, Cin, H, W
+    g.Cout, g.k, g.stride, g.pad, g.dil = Cout, k, stride, pad, dil
+    g.relu = 1
+    g.pos_mul, g.pos_add = pos_mul, pos_add
+    if win is not None:
+        g.win, g.Hl, g.Wl = 1, win[0], win[1]
+    us = ctypes.c_float(0.0)
+    code = (2 if nchw else 0) | (tile_code(tile, kt, stages) << 8)
+    _lib.check(_lib.lib().smk_bench_conv(_lib.DTYPE[dtype], code, ctypes.byref(g), int(bool(res)), iters,
+                                         ctypes.byref(us), _lib.current_stream_ptr()))
+    return us.value

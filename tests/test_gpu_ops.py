@@ -57,11 +57,14 @@ def test_conv_classes(cfg, dtype):
     for algo in ("naive", "mfma", "mfma_nchw", "naive_nchw"):
         y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo=algo).cpu().numpy()
         errs[algo] = rel_err(y, ref)
-    for tile in ((128, 128), (128, 64), (64, 128), (64, 64)):
-        y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo="mfma", tile=tile).cpu().numpy()
-        errs["mfma%s" % (tile,)] = rel_err(y, ref)
-        y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo="mfma_nchw", tile=tile).cpu().numpy()
-        errs["nchw%s" % (tile,)] = rel_err(y, ref)
+    # every instantiation of the kernel: workgroup tile x K-tile bytes x LDS ring depth x epilogue
+    for tile, kt in (((128, 128), 128), ((128, 128), 256), ((128, 64), 128), ((128, 64), 256),
+                     ((64, 128), 128), ((64, 128), 256), ((64, 64), 256)):
+        for stages in (2, 3, 4):
+            for algo in ("mfma", "mfma_nchw"):
+                y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo=algo, tile=tile, kt=kt,
+                               stages=stages).cpu().numpy()
+                errs["%s%s/%d/s%d" % (algo, tile, kt, stages)] = rel_err(y, ref)
     bad = {a: e for a, e in errs.items() if not e <= TOL[dtype]}
     assert not bad, "conv %s %s: %s (all: %s)" % (cfg, dtype, bad, errs)
 
@@ -76,13 +79,14 @@ def test_conv_epilogues(dtype):
     res = _rand(rng, 2, 96, 17, 17)
     base = O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64))
     xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
-    for algo in ("naive", "mfma"):
-        y = ops.conv2d(xd, w, b, relu=True, dtype=dtype, algo=algo).cpu().numpy()
-        assert rel_err(y, np.maximum(base, 0)) <= TOL[dtype]
-        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=1, dtype=dtype, algo=algo).cpu().numpy()
-        assert rel_err(y, np.maximum(base + _q(res, dtype), 0)) <= TOL[dtype]
-        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=2, dtype=dtype, algo=algo).cpu().numpy()
-        assert rel_err(y, np.maximum(base, 0) + _q(res, dtype)) <= TOL[dtype]
+    for algo, tile in (("naive", None), ("mfma", None), ("mfma", (128, 128)), ("mfma", (128, 64)),
+                       ("mfma", (64, 128)), ("mfma", (64, 64))):
+        y = ops.conv2d(xd, w, b, relu=True, dtype=dtype, algo=algo, tile=tile).cpu().numpy()
+        assert rel_err(y, np.maximum(base, 0)) <= TOL[dtype], (algo, tile)
+        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=1, dtype=dtype, algo=algo, tile=tile).cpu().numpy()
+        assert rel_err(y, np.maximum(base + _q(res, dtype), 0)) <= TOL[dtype], (algo, tile)
+        y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=2, dtype=dtype, algo=algo, tile=tile).cpu().numpy()
+        assert rel_err(y, np.maximum(base, 0) + _q(res, dtype)) <= TOL[dtype], (algo, tile)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
@@ -96,9 +100,9 @@ def test_conv_window_upsample_slice(dtype):
     ref = np.concatenate([O.conv2d(fp[b:b + 1, :, y:y + 15, x:x + 15], _q(w, dtype), None, 1, 1, 1)
                           for b, (y, x) in enumerate(pos)])
     fd = torch.from_numpy(f).cuda()
-    for algo in ("naive", "mfma"):
-        y = ops.conv2d(fd, w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4, dtype=dtype, algo=algo)
-        assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype], algo
+    for algo, tile in (("naive", None), ("mfma", None), ("mfma", (128, 64)), ("mfma", (64, 64))):
+        y = ops.conv2d(fd, w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4, dtype=dtype, algo=algo, tile=tile)
+        assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype], (algo, tile)
     x = _rand(rng, 2, 32, 15, 15)
     w2 = _rand(rng, 16, 32, 3, 3) / 17
     ref = O.conv2d(O.upsample_nearest(_q(x, dtype), 31), _q(w2, dtype), None, 1, 1, 1)
@@ -127,8 +131,11 @@ def test_heavy_real_shapes(dtype):
         x = _rand(rng, 1, cin, 31, 31)
         w = _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k)
         ref = O.conv2d(_q(x, dtype), _q(w, dtype), None, 1, pad, dil)
-        y = ops.conv2d(torch.from_numpy(x).cuda(), w, pad=pad, dil=dil, dtype=dtype).cpu().numpy()
-        assert rel_err(y, ref) <= TOL[dtype]
+        xd = torch.from_numpy(x).cuda()
+        for tile, kt, stages in ((None, 0, 0), ((128, 128), 128, 2), ((128, 128), 128, 4), ((128, 64), 256, 3),
+                                 ((64, 128), 128, 4), ((64, 64), 256, 2), ((64, 64), 256, 4)):
+            y = ops.conv2d(xd, w, pad=pad, dil=dil, dtype=dtype, tile=tile, kt=kt, stages=stages).cpu().numpy()
+            assert rel_err(y, ref) <= TOL[dtype], (cin, tile, kt, stages)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
