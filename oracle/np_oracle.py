@@ -266,6 +266,121 @@ class Oracle(object):
 
 
 # ------------------------------------------------------------------------------------
+# quantisation-aware oracle for the fp16 HIP path ("tight" fp16 gate)
+# ------------------------------------------------------------------------------------
+def q16(a):
+    """round to fp16 the way the device does (f64 -> f32 -> f16), keep computing in float64"""
+    return np.asarray(a).astype(np.float32).astype(np.float16).astype(np.float64)
+
+
+class QuantOracle(Oracle):
+    """The reference op sequence with the rounding points of the fp16 kernels:
+      * BatchNorm folded into the conv in float64, folded weights rounded to fp16, folded
+        bias kept in fp32 (engine.cpp: fold/pack_rows/upload_packed);
+      * every activation that the kernels STORE (NHWC, fp16) is rounded to fp16 after the fused
+        epilogue (bias, residual, ReLU); accumulation is exact here (fp32 on the device);
+      * tensors handed back to the caller (cls, loc, mask, refine logits) are fp32: not rounded.
+    Same call surface as ``Oracle``."""
+
+    def __init__(self, sd, variant="sharp"):
+        super(QuantOracle, self).__init__(sd, variant, np.float64)
+
+    def _fold(self, conv, bn=None):
+        w = self.sd[conv + ".weight"]
+        co = w.shape[0]
+        scale, shift = np.ones(co), np.zeros(co)
+        if bn is not None:
+            s = self.sd
+            scale = s[bn + ".weight"] / np.sqrt(s[bn + ".running_var"] + BN_EPS)
+            shift = s[bn + ".bias"] - s[bn + ".running_mean"] * scale
+        if conv + ".bias" in self.sd:
+            shift = shift + self.sd[conv + ".bias"]
+        return q16(w * scale.reshape(-1, 1, 1, 1)), shift.astype(np.float32).astype(np.float64)
+
+    def _fused(self, x, conv, bn=None, stride=1, pad=0, dil=1, act=False, res=None, res_after_relu=False,
+               store=True):
+        w, b = self._fold(conv, bn)
+        y = conv2d(x, w, b, stride, pad, dil)
+        if res is not None and not res_after_relu:
+            y = y + res
+        if act:
+            y = relu(y)
+        if res is not None and res_after_relu:
+            y = y + res
+        return q16(y) if store else y
+
+    def _bottleneck(self, x, p, stride, dil, ds):
+        pad2 = dil if dil > 1 else 2 - stride
+        out = self._fused(x, p + "conv1", p + "bn1", act=True)
+        out = self._fused(out, p + "conv2", p + "bn2", stride, pad2, dil, act=True)
+        if ds is not None:
+            k, s, pd = ds
+            residual = self._fused(x, p + "downsample.0", p + "downsample.1", s, pd, 1)
+        else:
+            residual = x
+        return self._fused(out, p + "conv3", p + "bn3", act=True, res=residual)
+
+    def resnet(self, x):
+        f = "features.features."
+        x = q16(x)                                                            # cvt_in
+        p0 = self._fused(x, f + "conv1", f + "bn1", 2, 0, act=True)
+        x = maxpool_3x3_s2_p1(p0)
+        for b in range(3):
+            x = self._bottleneck(x, f + "layer1.%d." % b, 1, 1, (1, 1, 0) if b == 0 else None)
+        p1 = x
+        for b in range(4):
+            x = self._bottleneck(x, f + "layer2.%d." % b, 2 if b == 0 else 1, 1, (3, 2, 0) if b == 0 else None)
+        p2 = x
+        for b in range(6):
+            x = self._bottleneck(x, f + "layer3.%d." % b, 1, 1 if b == 0 else 2, (3, 1, 1) if b == 0 else None)
+        return p0, p1, p2, x
+
+    def resdown(self, x):
+        feats = self.resnet(x)
+        d = "features.downsample.downsample."
+        y = self._fused(feats[3], d + "0", d + "1")
+        if y.shape[3] < 20:
+            y = y[:, :, 4:-4, 4:-4]
+        return feats, y
+
+    def forward_corr(self, p, kernel, search):
+        br = p.rstrip(".").split(".")[-1]
+        k = self._fused(kernel, p + "conv_kernel.0", p + "conv_kernel.1", act=True)
+        s = self._fused(search, p + "conv_search.0", p + "conv_search.1", act=True)
+        corr = q16(conv2d_dw_group(s, k))
+        self.dbg["zk_" + br], self.dbg["xs_" + br], self.dbg["corr_" + br] = k, s, corr
+        return corr
+
+    def head(self, p, feature):
+        h = self._fused(feature, p + "head.0", p + "head.1", act=True)
+        self.dbg["head0_" + p.rstrip(".").split(".")[-1]] = h
+        return self._fused(h, p + "head.3", store=False)
+
+    def refine(self, f, corr_feature, pos):
+        r = "refine_model."
+        y, x = int(pos[0]), int(pos[1])
+        pz = lambda t, n: np.pad(t, ((0, 0), (0, 0), (n, n), (n, n)))
+        p0 = pz(f[0], 16)[:, :, 4 * y:4 * y + 61, 4 * x:4 * x + 61]
+        p1 = pz(f[1], 8)[:, :, 2 * y:2 * y + 31, 2 * x:2 * x + 31]
+        p2 = pz(f[2], 4)[:, :, y:y + 15, x:x + 15]
+        p3 = corr_feature[:, :, y, x].reshape(-1, 256, 1, 1)
+        out = q16(conv_transpose_1x1_input(p3, q16(self.sd[r + "deconv.weight"]),
+                                           self.sd[r + "deconv.bias"].astype(np.float32).astype(np.float64)))
+
+        def stage(out, pf, h, v, post, size, store):
+            ha = self._fused(out, r + h + ".0", pad=1, act=True)
+            hb = self._fused(ha, r + h + ".2", pad=1, act=True)
+            va = self._fused(pf, r + v + ".0", pad=1, act=True)
+            s = self._fused(va, r + v + ".2", pad=1, act=True, res=hb, res_after_relu=True)
+            return self._fused(upsample_nearest(s, size), r + post, pad=1, store=store)
+
+        out = stage(out, p2, "h2", "v2", "post0", 31, True)
+        out = stage(out, p1, "h1", "v1", "post1", 61, True)
+        out = stage(out, p0, "h0", "v0", "post2", 127, False)
+        return out.reshape(-1, 127 * 127)
+
+
+# ------------------------------------------------------------------------------------
 # host-side decode used by the parity tests (tools/test.py:205-254), restated
 # ------------------------------------------------------------------------------------
 def generate_anchor(score_size=25, stride=8, ratios=(0.33, 0.5, 1, 2, 3), scales=(8,)):

@@ -106,7 +106,9 @@ template <int SPR> __device__ __forceinline__ int swz(int row) {
 //   K tile sits behind the last MFMA group of the tile, so that it is covered by matrix-pipe
 //   time instead of exposing it.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
+// ABL (measurement only, results are garbage when != 0): 1 no MFMA, 2 no LDS-DMA in the steady
+// loop, 3 no fragment reads in the loops, 4 LDS-DMA only, 5 no LDS-DMA of the weight operand
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     typedef Traits<T> TR;
@@ -264,7 +266,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
     auto mma_part = [&](int par, int q0, int q1) {
 #pragma unroll
-        for (int q = q0; q < q1; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+        for (int q = q0; q < q1; ++q) {
+            if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(fa[par][q >> 1]), "v"(fb[par][q & 1]));
+            else TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+        }
+    };
+    auto loop_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
+        if constexpr (ABL != 3 && ABL != 4) read_frags(buf, s, a, b);
     };
 
     // ---- prologue: up to AHEAD tiles in flight, tile 0 landed, its first fragments in registers
@@ -304,9 +312,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (s + 1 < NKS) {
                 mma_part(s & 1, 0, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
-                for (int j = (s * NP) / PS; j < ((s + 1) * NP) / PS; ++j) issue_piece(j, kt + AHEAD, islot);
+                for (int j = (s * NP) / PS; j < ((s + 1) * NP) / PS; ++j)
+                    if (ABL != 2 && !(ABL == 5 && j >= RA)) issue_piece(j, kt + AHEAD, islot);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_part(s & 1, 1, 4);
             } else {
@@ -314,12 +323,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 // hand-over: my pieces of tile kt+1 have landed (AHEAD-1 younger tiles may still be
                 // in flight), all my LDS reads of tile kt are complete ...
-                wait_vmcnt<(AHEAD - 1) * NP>();
+                wait_vmcnt<ABL == 2 ? 0 : (ABL == 5 ? (AHEAD - 1) * RA : (AHEAD - 1) * NP)>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // ... and so for every other wave: tile kt+1 is readable, the slot of tile kt is free
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                read_frags(nxt, 0, fa[0], fb[0]);
+                loop_frags(nxt, 0, fa[0], fb[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_part(s & 1, 2, 4);
             }
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (s + 1 < NKS) {
                 mma_part(s & 1, 0, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_part(s & 1, 1, 4);
             } else {
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    read_frags(nxt, 0, fa[0], fb[0]);
+                    loop_frags(nxt, 0, fa[0], fb[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mma_part(s & 1, 2, 4);
@@ -552,6 +561,20 @@ static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
 template <typename T, int OM>
 static int launch_tiles(const ConvParams &p, TileChoice t, hipStream_t s) {
     const bool k256 = t.kt == 256;
+    if constexpr (sizeof(T) == 2 && OM == OUT_NHWC) {
+        if (g_tune.ablate && t.bm == 128 && t.bn == 128 && !k256) {
+            const int tilesM = (p.M + 127) / 128, tilesN = (p.Nst + 127) / 128;
+            dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
+#define SMK_ABL(A)                                                                                             \
+    if (g_tune.ablate == A) {                                                                                  \
+        if (t.stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 2, A>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 3, A>), grid, dim3(256), 0, s, p);     \
+        return hipGetLastError() == hipSuccess ? 0 : -4;                                                      \
+    }
+            SMK_ABL(1) SMK_ABL(2) SMK_ABL(3) SMK_ABL(4) SMK_ABL(5)
+#undef SMK_ABL
+        }
+    }
     if (t.bm == 128 && t.bn == 128)
         return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(p, t.stages, s);
     if (t.bm == 128 && t.bn == 64)

@@ -936,6 +936,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
+    else if (!strcmp(key, "ablate")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "ablate 0..5"); g_tune.ablate = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
     return 0;

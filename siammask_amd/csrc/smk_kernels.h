@@ -62,6 +62,7 @@ struct Tuning {
     int min_blocks_x16 = 16;   // shrink tiles while grid < CUs * min_blocks_x16/16
     int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2..4
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
+    int ablate = 0;            // measurement only: ablated variants of the 128x128x128 kernel (see conv_igemm.hip)
 };
 extern Tuning g_tune;
 

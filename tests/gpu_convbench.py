@@ -4,8 +4,11 @@
 (smk_bench_conv).  Output: JSON {batch: {layer: {"gflop":…, "runs": {"128x128/128/s3": us, …}}}}.
 Used to derive the tile heuristics in conv_igemm.hip::choose_tile (results under profiles/)."""
 import json
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: F401
 
