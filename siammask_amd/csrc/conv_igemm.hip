@@ -93,24 +93,36 @@ template <int SPR> __device__ __forceinline__ int swz(int row) {
 
 // ---------------------------------------------------------------------------------------------
 // conv_igemm_kernel<T, WM, WN, WK, KT, OUT_MODE, NSTAGE>
-//   256 threads = 4 waves arranged WM x WN x WK (WM*WN*WK == 4).  EVERY wave owns a 64x64
-//   accumulator tile (2x2 MFMA 32x32 fragments): the LDS->register traffic per MFMA is the
-//   same for all workgroup shapes (4 ds_read_b128 per 4 MFMAs).  Workgroup tile = 64*WM x 64*WN;
-//   when WK > 1 the waves of a K-group split the k-steps of every K tile between them and the
-//   partial sums are added in the epilogue (through LDS), so small tiles stay LDS-efficient.
-//   K tile = KT bytes of K per row (128 or 256), staged by LDS-DMA into an NSTAGE-deep ring.
+//   512 threads = 4 CONSUMER waves + 4 PRODUCER waves (wave specialisation).
+//   Measured on the previous all-waves-do-everything kernel (profiles/r01_v3_ablation_128x128.json):
+//   LDS-DMA issue, LDS fragment reads and MFMAs serialise inside an in-order wave
+//   (B=64 l3.0.ds: DMA alone 452 us, MFMA + reads alone 511 us, together 754 us).  Here the
+//   producers only gather addresses and issue the LDS-DMA, the consumers only read fragments and
+//   issue MFMAs, so a producer stalled on the memory pipe never blocks the matrix pipe.
 //
-//   Software pipeline (per wave, per K tile): the fragments of k-step s+1 are read from LDS
-//   while the MFMAs of step s run (register double buffer), the LDS-DMA pieces of tile
-//   kt+NSTAGE-1 are issued a few at a time between the MFMA groups, and the single barrier per
-//   K tile sits behind the last MFMA group of the tile, so that it is covered by matrix-pipe
-//   time instead of exposing it.
+//   Consumers are arranged WM x WN x WK (WM*WN*WK == 4); EVERY consumer owns a 64x64 accumulator
+//   tile (2x2 MFMA 32x32 fragments), so the LDS->register traffic per MFMA is the same for all
+//   workgroup shapes (4 ds_read_b128 per 4 MFMAs).  Workgroup tile = 64*WM x 64*WN; when WK > 1
+//   the consumers of a K-group split the k-steps of every K tile between them and the partial
+//   sums are added in the epilogue (through LDS), so small tiles stay LDS-efficient.
+//   K tile = KT bytes of K per row (128 or 256), staged into an NSTAGE-deep LDS ring.
+//
+//   Hand-over protocol, ONE s_barrier per K tile for all eight waves.  barrier(kt) means
+//   "tile kt is complete in LDS and nobody reads tile kt-1 any more":
+//     producer: wait vmcnt(own pieces of tile kt) ; barrier(kt) ; issue tile kt+NSTAGE-1 into the
+//               slot tile kt-1 occupied
+//     consumer: barrier(kt) ; read fragments of tile kt / MFMA (its reads of tile kt are all
+//               consumed by MFMAs before it reaches barrier(kt+1))
 // ---------------------------------------------------------------------------------------------
-// ABL (measurement only, results are garbage when != 0): 1 no MFMA, 2 no LDS-DMA in the steady
-// loop, 3 no fragment reads in the loops, 4 LDS-DMA only, 5 no LDS-DMA of the weight operand
-template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE, int ABL = 0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    static_assert(WM * WN * WK == 4, "four waves per workgroup");
+template <int STAGE_BYTES, int NSTAGE, int EPI> struct WgPerCu {
+    static constexpr int lds = CMax<STAGE_BYTES * NSTAGE, EPI>::v;
+    static constexpr int v = (160 * 1024 / lds) >= 2 ? 2 : 1;     // workgroups per CU the LDS admits (cap 2)
+};
+
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
+__global__ __launch_bounds__(512, (2 * WgPerCu<64 * (WM + WN) * KT, NSTAGE, 4 * 64 * (OUT_MODE == OUT_NCHW_F32 ? 65 : 68) * 4>::v))
+void conv_igemm_kernel(const ConvParams p) {
+    static_assert(WM * WN * WK == 4, "four consumer waves per workgroup");
     typedef Traits<T> TR;
     typedef typename TR::frag_t frag_t;
     constexpr int VE = TR::VE;
@@ -118,26 +130,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BK = KT / (int)sizeof(T);
     constexpr int SPR = KT / 16;               // 16-byte slots per LDS row
     constexpr int RPR = 256 / SPR;             // rows filled by one round of 256 LDS-DMA pieces
-    constexpr int RA = BM / RPR, RB = BN / RPR, NP = RA + RB;   // pieces per thread per K tile
-    constexpr int NKS = (KT / 32) / WK;        // k-steps (32 bytes of K) per K tile per wave
+    constexpr int RA = BM / RPR, RB = BN / RPR, NP = RA + RB;   // pieces per producer thread per K tile
+    constexpr int NKS = (KT / 32) / WK;        // k-steps (32 bytes of K) per K tile per consumer
     static_assert(NKS >= 2 && NKS % 2 == 0, "register double buffer needs an even step count");
     constexpr int AHEAD = NSTAGE - 1;          // K tiles in flight
     static_assert(AHEAD >= 1 && AHEAD <= 3, "ring depth 2..4");
     constexpr int STAGE_BYTES = (BM + BN) * KT;
-    constexpr int EROWS = OUT_MODE == OUT_NCHW_F32 ? 64 : 32;   // accumulator rows per epilogue pass
     constexpr int LDE = OUT_MODE == OUT_NCHW_F32 ? 65 : 68;
-    constexpr int EPI_BYTES = 4 * EROWS * LDE * 4;
+    constexpr int EPI_BYTES = 4 * 64 * LDE * 4;                 // four 64x64 f32 accumulator tiles
     constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
     const int g = blockIdx.z;
-    const int cin_off = p.cin_off + g * p.g_cin_off;
-    const T *wgt = (const T *)p.wgt + (size_t)g * p.g_wgt_off * p.Kpad;
-    const float *bias = p.bias + g * p.g_wgt_off;
     const int cout_off = p.cout_off + g * p.g_cout_off;
+    const float *bias = p.bias + g * p.g_wgt_off;
 
     // XCD-aware tile order (p.xcd_mode): workgroup b runs on XCD b % 8 (observed dispatch
     // order, used for speed only).  Mode 1 hands every XCD a contiguous range of the tm-major
@@ -158,285 +166,263 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         tm = t / tilesN; tn = t - tm * tilesN;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-
-    // LDS-DMA writes lane-linear: thread `tid` fills (row tid/SPR [+RPR*i], physical slot tid%SPR).
-    // The XOR swizzle therefore goes on the SOURCE: this thread fetches the logical 16-byte
-    // slot  phys ^ swz(row)  of its row, and the fragment reads apply the same XOR.
-    const int lrow = tid / SPR;
-    const int slot = (tid % SPR) ^ swz<SPR>(lrow);      // swz(lrow + RPR*i) == swz(lrow)
-
-    // ---- per-thread row bookkeeping for the A gather --------------------------------------
-    RowInfo ri[RA];
-    bool rvalid[RA];
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        int m = m0 + lrow + RPR * i;
-        rvalid[i] = m < p.M;
-        ri[i] = row_info(p, rvalid[i] ? m : 0, p.pos);
-    }
-    const char *in = (const char *)p.in;
-    const long zero_off = (const char *)p.zero - in;   // 16 KB of zeros: source of all padding
-    const char *wsrc[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-        wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + RPR * i) * p.Kpad + slot * VE);
     const int nk = (p.K + BK - 1) / BK;
 
-    // This thread always fetches the same 16-byte slot of every K tile, i.e. K index
-    // kt*BK + slot*VE.  Its (tap, channel) position is decoded per tile with a shift (Ci is a
-    // power of two on this path; p.ci_shift < 0 selects the division fallback).  When a K tile
-    // never straddles a tap (Ci >= BK) the tap is wave-uniform and the per-row source offsets
-    // are recomputed only when it changes (scalar branch); otherwise they are recomputed per
-    // tile.  Padding (conv zero padding, rows >= M, K tail) reads the zero page, so the loads are
-    // branch-free.
-    const bool tap_uniform = p.ci_shift >= 0 && p.Ci >= BK;
-    int cur_tap_s = -1;                                // wave-uniform tap of the last decode
-    int cur_c = 0;
-    long a_off[RA];                                    // byte offsets relative to `in`
-    auto tap_offsets = [&](int tap) {
-        const int kh_i = (tap * p.kw_magic) >> 16;
-        const int kw_i = tap - kh_i * p.kw;
-        const bool tap_ok = kh_i < p.kh;
+    floatx16 acc[2][2];                // consumers only
+
+    if (wave >= 4) {
+        // =========================== PRODUCER: gather + LDS-DMA ===============================
+        const int ptid = tid - 256, pw = wave - 4;
+        const int cin_off = p.cin_off + g * p.g_cin_off;
+        const T *wgt = (const T *)p.wgt + (size_t)g * p.g_wgt_off * p.Kpad;
+        // LDS-DMA writes lane-linear: thread ptid fills (row ptid/SPR [+RPR*i], physical slot
+        // ptid%SPR).  The XOR swizzle therefore goes on the SOURCE: this thread fetches the logical
+        // 16-byte slot  phys ^ swz(row)  of its row, and the fragment reads apply the same XOR.
+        const int lrow = ptid / SPR;
+        const int slot = (ptid % SPR) ^ swz<SPR>(lrow);     // swz(lrow + RPR*i) == swz(lrow)
+        RowInfo ri[RA];
+        bool rvalid[RA];
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int ly = ri[i].ly0 + kh_i * p.dil, lx = ri[i].lx0 + kw_i * p.dil;
-            bool ok = rvalid[i] & tap_ok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
-            int sy, sx;
-            if (p.ups) {                               // nearest upsampling (uniform branch)
-                sy = (ly * p.Hs) / p.Hl;
-                sx = (lx * p.Ws) / p.Wl;
-            } else {
-                sy = ly + ri[i].oy_org;
-                sx = lx + ri[i].ox_org;
-            }
-            ok = ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
-            const long off = (((long)(ri[i].b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off) * (long)sizeof(T);
-            a_off[i] = ok ? off : zero_off;
+            int m = m0 + lrow + RPR * i;
+            rvalid[i] = m < p.M;
+            ri[i] = row_info(p, rvalid[i] ? m : 0, p.pos);
         }
-    };
-    auto set_tile = [&](int kt) {
-        if (tap_uniform) {
-            const int k0 = kt * BK;
-            const int tap = k0 >> p.ci_shift;
-            cur_c = (k0 & (p.Ci - 1)) + slot * VE;
-            if (tap != cur_tap_s) {
-                cur_tap_s = tap;
+        const char *in = (const char *)p.in;
+        const long zero_off = (const char *)p.zero - in;   // 16 KB of zeros: source of all padding
+        const char *wsrc[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + RPR * i) * p.Kpad + slot * VE);
+
+        // This thread always fetches the same 16-byte slot of every K tile, i.e. K index
+        // kt*BK + slot*VE.  Its (tap, channel) position is decoded per tile with a shift (Ci is a
+        // power of two on this path; p.ci_shift < 0 selects the division fallback).  When a K tile
+        // never straddles a tap (Ci >= BK) the tap is wave-uniform and the per-row source offsets
+        // are recomputed only when it changes (scalar branch); otherwise they are recomputed per
+        // tile.  Padding (conv zero padding, rows >= M, K tail) reads the zero page, so the loads
+        // are branch-free.
+        const bool tap_uniform = p.ci_shift >= 0 && p.Ci >= BK;
+        int cur_tap_s = -1;                                // wave-uniform tap of the last decode
+        int cur_c = 0;
+        long a_off[RA];                                    // byte offsets relative to `in`
+        auto tap_offsets = [&](int tap) {
+            const int kh_i = (tap * p.kw_magic) >> 16;
+            const int kw_i = tap - kh_i * p.kw;
+            const bool tap_ok = kh_i < p.kh;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ly = ri[i].ly0 + kh_i * p.dil, lx = ri[i].lx0 + kw_i * p.dil;
+                bool ok = rvalid[i] & tap_ok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
+                int sy, sx;
+                if (p.ups) {                               // nearest upsampling (uniform branch)
+                    sy = (ly * p.Hs) / p.Hl;
+                    sx = (lx * p.Ws) / p.Wl;
+                } else {
+                    sy = ly + ri[i].oy_org;
+                    sx = lx + ri[i].ox_org;
+                }
+                ok = ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
+                const long off = (((long)(ri[i].b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off) * (long)sizeof(T);
+                a_off[i] = ok ? off : zero_off;
+            }
+        };
+        auto set_tile = [&](int kt) {
+            if (tap_uniform) {
+                const int k0 = kt * BK;
+                const int tap = k0 >> p.ci_shift;
+                cur_c = (k0 & (p.Ci - 1)) + slot * VE;
+                if (tap != cur_tap_s) {
+                    cur_tap_s = tap;
+                    tap_offsets(tap);
+                }
+            } else {
+                const int k = kt * BK + slot * VE;
+                int tap;
+                if (p.ci_shift >= 0) { tap = k >> p.ci_shift; cur_c = k & (p.Ci - 1); }
+                else { tap = k / p.Ci; cur_c = k - tap * p.Ci; }
                 tap_offsets(tap);
             }
-        } else {
-            const int k = kt * BK + slot * VE;
-            int tap;
-            if (p.ci_shift >= 0) { tap = k >> p.ci_shift; cur_c = k & (p.Ci - 1); }
-            else { tap = k / p.Ci; cur_c = k - tap * p.Ci; }
-            tap_offsets(tap);
-        }
-    };
-    // LDS-DMA piece j (0..NP-1) of K tile kt into ring slot `buf`
-    auto issue_piece = [&](int j, int kt, int buf) {
-        unsigned char *sA = smem + buf * STAGE_BYTES + wave * 1024;
-        if (j < RA) {
-            glds16(in + a_off[j] + (long)cur_c * (long)sizeof(T), sA + j * 4096);
-        } else {
-            glds16(wsrc[j - RA] + (long)kt * KT, sA + BM * KT + (j - RA) * 4096);
-        }
-    };
+        };
+        // all NP pieces of K tile kt into ring slot `buf`
+        auto issue_tile = [&](int kt, int buf) {
+            unsigned char *sA = smem + buf * STAGE_BYTES + pw * 1024;
+            const long cb = (long)cur_c * (long)sizeof(T), kb = (long)kt * KT;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) glds16(in + a_off[j] + cb, sA + j * 4096);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) glds16(wsrc[j] + kb, sA + BM * KT + j * 4096);
+        };
 
-    floatx16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- fragment addressing ------------------------------------------------------------------
-    const int frow = lane & 31, fhalf = lane >> 5;
-    const int fsw = swz<SPR>(frow);                    // swz(64*w + 32*i + frow) == swz(frow)
-    const int a_row_off = (wm * 64 + frow) * KT;
-    const int b_row_off = BM * KT + (wn * 64 + frow) * KT;
-    frag_t fa[2][2], fb[2][2];                         // [step parity][fragment]
-    auto read_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
-        const unsigned char *sb = smem + buf * STAGE_BYTES;
-        const int so = (((s * WK + wk) * 2 + fhalf) ^ fsw) << 4;
-        a[0] = *(const frag_t *)(sb + a_row_off + so);
-        a[1] = *(const frag_t *)(sb + a_row_off + 32 * KT + so);
-        b[0] = *(const frag_t *)(sb + b_row_off + so);
-        b[1] = *(const frag_t *)(sb + b_row_off + 32 * KT + so);
-    };
-    // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
-    auto mma_part = [&](int par, int q0, int q1) {
-#pragma unroll
-        for (int q = q0; q < q1; ++q) {
-            if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(fa[par][q >> 1]), "v"(fb[par][q & 1]));
-            else TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
-        }
-    };
-    auto loop_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
-        if constexpr (ABL != 3 && ABL != 4) read_frags(buf, s, a, b);
-    };
-
-    // ---- prologue: up to AHEAD tiles in flight, tile 0 landed, its first fragments in registers
-#pragma unroll
-    for (int tt = 0; tt < AHEAD; ++tt)
-        if (tt < nk) {
-            set_tile(tt);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) issue_piece(j, tt, tt);
-        }
-    wait_tiles<NP>((nk < AHEAD ? nk : AHEAD) - 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(0, 0, fa[0], fb[0]);
-
-    // The LDS-DMA pieces of a tile are spread over the first PS k-steps of the iteration that
-    // issues it; the last k-step carries the hand-over to the next tile instead.
-    constexpr int PS = NKS - 1;
-    int cur = 0;                       // ring slot holding tile kt
-    int kt = 0;
-    // Issue order inside a k-step (pinned with sched_barrier; hipcc waits lgkmcnt(0) for LDS data,
-    // so a read must be old by the time the next wait comes):
-    //   MFMA 0 of step s                      <- waits for the fragments read one step ago
-    //   ds_read fragments of step s+1, LDS-DMA pieces of tile kt+AHEAD
-    //   MFMA 1..3 of step s                   <- ~100 cycles of matrix pipe cover the reads
-    // The last k-step of a tile carries the hand-over instead: MFMA 0,1 | wait for tile kt+1,
-    // barrier, read its first fragments | MFMA 2,3.
-    // ---- steady state: tile kt+AHEAD exists, so every iteration issues NP pieces ------------
-    for (; kt + AHEAD < nk; ++kt) {
-        int islot = cur + AHEAD;
-        if (islot >= NSTAGE) islot -= NSTAGE;
-        int nxt = cur + 1;
-        if (nxt == NSTAGE) nxt = 0;
-        set_tile(kt + AHEAD);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            if (s + 1 < NKS) {
-                mma_part(s & 1, 0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-#pragma unroll
-                for (int j = (s * NP) / PS; j < ((s + 1) * NP) / PS; ++j)
-                    if (ABL != 2 && !(ABL == 5 && j >= RA)) issue_piece(j, kt + AHEAD, islot);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_part(s & 1, 1, 4);
-            } else {
-                mma_part(s & 1, 0, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                // hand-over: my pieces of tile kt+1 have landed (AHEAD-1 younger tiles may still be
-                // in flight), all my LDS reads of tile kt are complete ...
-                wait_vmcnt<ABL == 2 ? 0 : (ABL == 5 ? (AHEAD - 1) * RA : (AHEAD - 1) * NP)>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // ... and so for every other wave: tile kt+1 is readable, the slot of tile kt is free
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                loop_frags(nxt, 0, fa[0], fb[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_part(s & 1, 2, 4);
+        for (int tt = 0; tt < AHEAD; ++tt)
+            if (tt < nk) {
+                set_tile(tt);
+                issue_tile(tt, tt);
             }
+        int islot = AHEAD;                                 // slot of tile kt + AHEAD
+        if (islot == NSTAGE) islot = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt: my pieces have landed; tiles kt+1 .. min(kt+AHEAD-1, nk-1) may still be in flight
+            int younger = nk - 1 - kt;
+            if (younger > AHEAD - 1) younger = AHEAD - 1;
+            wait_tiles<NP>(younger);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + AHEAD < nk) {
+                set_tile(kt + AHEAD);
+                issue_tile(kt + AHEAD, islot);
+            }
+            if (++islot == NSTAGE) islot = 0;
         }
-        cur = nxt;
-    }
-    // ---- drain: nothing left to issue --------------------------------------------------------
-    for (; kt < nk; ++kt) {
-        int nxt = cur + 1;
-        if (nxt == NSTAGE) nxt = 0;
+    } else {
+        // =========================== CONSUMER: LDS fragments + MFMA ===========================
+        const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            if (s + 1 < NKS) {
-                mma_part(s & 1, 0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_part(s & 1, 1, 4);
-            } else {
-                mma_part(s & 1, 0, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < nk) {
-                    wait_tiles<NP>(nk - 2 - kt);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    loop_frags(nxt, 0, fa[0], fb[0]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int frow = lane & 31, fhalf = lane >> 5;
+        const int fsw = swz<SPR>(frow);                    // swz(64*w + 32*i + frow) == swz(frow)
+        const int a_row_off = (wm * 64 + frow) * KT;
+        const int b_row_off = BM * KT + (wn * 64 + frow) * KT;
+        frag_t fa[2][2], fb[2][2];                         // [step parity][fragment]
+        auto read_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
+            const unsigned char *sb = smem + buf * STAGE_BYTES;
+            const int so = (((s * WK + wk) * 2 + fhalf) ^ fsw) << 4;
+            a[0] = *(const frag_t *)(sb + a_row_off + so);
+            a[1] = *(const frag_t *)(sb + a_row_off + 32 * KT + so);
+            b[0] = *(const frag_t *)(sb + b_row_off + so);
+            b[1] = *(const frag_t *)(sb + b_row_off + 32 * KT + so);
+        };
+        // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
+        auto mma_part = [&](int par, int q0, int q1) {
+#pragma unroll
+            for (int q = q0; q < q1; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+        };
+
+        __builtin_amdgcn_s_barrier();                      // barrier(0): tile 0 is complete
+        asm volatile("" ::: "memory");
+        read_frags(0, 0, fa[0], fb[0]);
+        // Issue order inside a k-step (pinned with sched_barrier):
+        //   ds_read fragments of step s+1          (register double buffer)
+        //   MFMA 0..3 of step s                    <- hipcc waits lgkmcnt(4): only for the fragments
+        //                                             read one step ago; 128 cycles of matrix pipe
+        //                                             cover the new reads
+        // The last k-step of a tile carries the hand-over: MFMA 0,1 | barrier(kt+1), first
+        // fragments of tile kt+1 | MFMA 2,3.
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            int nxt = cur + 1;
+            if (nxt == NSTAGE) nxt = 0;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s == 0) {
+                    // (hipcc waits lgkmcnt(0) at the loop head: keep the new reads behind MFMA 0)
+                    mma_part(0, 0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(cur, 1, fa[1], fb[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(0, 1, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (s + 1 < NKS) {
+                    read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(s & 1, 0, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    mma_part(s & 1, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 1 < nk) {
+                        // all my LDS reads of tile kt are complete (the MFMAs above consumed them)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();          // barrier(kt+1)
+                        asm volatile("" ::: "memory");
+                        read_frags(nxt, 0, fa[0], fb[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(s & 1, 2, 4);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                mma_part(s & 1, 2, 4);
             }
+            cur = nxt;
         }
-        cur = nxt;
     }
     __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (per-wave region) -> sum over the K-group -> fused
-    //      bias/res/relu -> global.  EROWS accumulator rows per pass.
-    float *e = (float *)smem + wave * (EROWS * LDE);
-    const float *eg = (const float *)smem + (wave - wk) * (EROWS * LDE);   // first wave of my K-group
+    // ---- epilogue: the four accumulator tiles -> LDS -> (sum over the K-group) -> fused
+    //      bias/res/relu -> global, by all eight waves ----------------------------------------
+    if (wave < 4) {
+        float *e = (float *)smem + wave * (64 * LDE);
+        const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
-    for (int ep = 0; ep < 64 / EROWS; ++ep) {
-        if (ep > 0) __syncthreads();
-#pragma unroll
-        for (int ii = 0; ii < EROWS / 32; ++ii)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = ep * (EROWS / 32) + ii;
-                    int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                     int col = j * 32 + frow;
                     e[row * LDE + col] = acc[i][j][r];
                 }
-        __syncthreads();
-
-        if (OUT_MODE == OUT_NHWC) {
-            // 16 lanes x 4 channels per row, 4 rows per pass; the WK waves of a K-group share the rows
-            constexpr int RW = EROWS / WK;        // rows handled by this wave
-            const int c4 = (lane & 15) * 4, r0 = lane >> 4;
-            const int n = n0 + wn * 64 + c4;
-            if (n < p.Nst) {
-                const floatx4 bv = *(const floatx4 *)(bias + n);
-                T *out = (T *)p.out;
-                const T *res = (const T *)p.res;
+    }
+    __syncthreads();
+    const float *ebase = (const float *)smem;
+    // region of consumer (wm, wn, wk): ((wm*WN + wn)*WK + wk) * 64*LDE floats
+    if (OUT_MODE == OUT_NHWC) {
+        constexpr int LPR = BN / 4;          // threads per output row (4 channels each)
+        constexpr int RPP = 512 / LPR;       // rows per pass
+        const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
+        const int n = n0 + c4;
+        if (n < p.Nst) {
+            const floatx4 bv = *(const floatx4 *)(bias + n);
+            T *out = (T *)p.out;
+            const T *res = (const T *)p.res;
+            const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
+#pragma unroll 4
+            for (int pass = 0; pass < BM / RPP; ++pass) {
+                const int row = pass * RPP + r0;
+                const int m = m0 + row;
+                if (m < p.M) {
+                    const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
+                    floatx4 v = *(const floatx4 *)er;
 #pragma unroll
-                for (int pass = 0; pass < RW / 4; ++pass) {
-                    const int row = wk * RW + pass * 4 + r0;
-                    const int m = m0 + wm * 64 + ep * EROWS + row;
-                    if (m < p.M) {
-                        floatx4 v = *(const floatx4 *)(eg + row * LDE + c4);
-#pragma unroll
-                        for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(eg + q * (EROWS * LDE) + row * LDE + c4);
-                        v += bv;
-                        floatx4 rv = {0.f, 0.f, 0.f, 0.f};
-                        if (p.res_mode != RES_NONE)
-                            rv = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n);
-                        if (p.res_mode == RES_PRE_RELU) v += rv;
-                        if (p.relu) {
-                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                        }
-                        if (p.res_mode == RES_POST_RELU) v += rv;
-                        TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
+                    for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(er + q * (64 * LDE));
+                    v += bv;
+                    floatx4 rv = {0.f, 0.f, 0.f, 0.f};
+                    if (p.res_mode != RES_NONE)
+                        rv = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n);
+                    if (p.res_mode == RES_PRE_RELU) v += rv;
+                    if (p.relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                     }
+                    if (p.res_mode == RES_POST_RELU) v += rv;
+                    TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
                 }
             }
-        } else {
-            // NCHW f32: lanes run along m (contiguous positions of one channel plane)
-            const int row = lane;                              // EROWS == 64
-            const int m = m0 + wm * 64 + row;
-            if (m < p.M) {
-                const int hw = p.Ho * p.Wo;
-                const int b = m / hw, pos = m - b * hw;
-                float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
-                constexpr int CW = 64 / WK;                    // columns handled by this wave
-#pragma unroll 4
-                for (int jj = 0; jj < CW; ++jj) {
-                    const int j = wk * CW + jj;
-                    const int n = n0 + wn * 64 + j;
-                    if (n < p.N) {
-                        float v = eg[row * LDE + j];
+        }
+    } else {
+        // NCHW f32: threads run along m (contiguous positions of one channel plane)
+        constexpr int CG = 512 / BM;         // column groups processed concurrently
+        const int row = tid % BM, cg = tid / BM;
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, pos = m - b * hw;
+            float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
+            const float *er = ebase + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
+            for (int j = cg; j < BN; j += CG) {
+                const int n = n0 + j;
+                if (n < p.N) {
+                    const float *ec = er + ((j >> 6) * WK) * (64 * LDE) + (j & 63);
+                    float v = ec[0];
 #pragma unroll
-                        for (int q = 1; q < WK; ++q) v += eg[q * (EROWS * LDE) + row * LDE + j];
-                        v += bias[n];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        obase[(size_t)n * hw] = v;
-                    }
+                    for (int q = 1; q < WK; ++q) v += ec[q * (64 * LDE)];
+                    v += bias[n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    obase[(size_t)n * hw] = v;
                 }
             }
         }
@@ -544,37 +530,23 @@ static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
     if (stages < 2) stages = 2;
     if constexpr (MAXST >= 4) {
         if (stages == 4) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(512), 0, s, p);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
     if constexpr (MAXST >= 3) {
         if (stages == 3) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(512), 0, s, p);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(512), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <typename T, int OM>
 static int launch_tiles(const ConvParams &p, TileChoice t, hipStream_t s) {
     const bool k256 = t.kt == 256;
-    if constexpr (sizeof(T) == 2 && OM == OUT_NHWC) {
-        if (g_tune.ablate && t.bm == 128 && t.bn == 128 && !k256) {
-            const int tilesM = (p.M + 127) / 128, tilesN = (p.Nst + 127) / 128;
-            dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
-#define SMK_ABL(A)                                                                                             \
-    if (g_tune.ablate == A) {                                                                                  \
-        if (t.stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 2, A>), grid, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 3, A>), grid, dim3(256), 0, s, p);     \
-        return hipGetLastError() == hipSuccess ? 0 : -4;                                                      \
-    }
-            SMK_ABL(1) SMK_ABL(2) SMK_ABL(3) SMK_ABL(4) SMK_ABL(5)
-#undef SMK_ABL
-        }
-    }
     if (t.bm == 128 && t.bn == 128)
         return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(p, t.stages, s);
     if (t.bm == 128 && t.bn == 64)
