@@ -128,7 +128,7 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const float
 int smk_set_graph_mode(smk_ctx *ctx, int enable);
 
 /* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured
- * work): "xcd_mode" 0|1|2, "force_tile" 0..4, "min_blocks_x16", "stages" 0|2|3|4, "kt" 0|128|256 (K-tile bytes), "concurrency" 0|1
+ * work): "xcd_mode" 0|1|2, "force_tile" 0..5, "min_blocks_x16", "stages" 0|2|3|4, "kt" 0|128|256 (K-tile bytes), "concurrency" 0|1
  * (the latter applies to contexts created afterwards). */
 int smk_tune(const char *key, int value);
 
@@ -170,7 +170,7 @@ typedef struct smk_conv_geom {
 
 /* algo: low byte 0 = MFMA kernel, NHWC epilogue; 1 = naive kernel, NHWC epilogue;
  *                2 = MFMA kernel, NCHW-f32 epilogue; 3 = naive kernel, NCHW-f32 epilogue;
- *       second byte: bits 0-3 tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64;
+ *       second byte: bits 0-3 tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64, 5 256x128;
  *                    bits 4-5 K tile 0 auto, 1 = 128 B, 2 = 256 B; bits 6-7 LDS ring depth
  *                    0 auto, 1..3 = 2..4 stages.
  * w_host [Cout,cin_len,k,k], b_host [Cout] or NULL (host); x_dev, res_dev [B,Cout,Ho,Wo],

@@ -93,14 +93,14 @@ template <int SPR> __device__ __forceinline__ int swz(int row) {
 
 // ---------------------------------------------------------------------------------------------
 // conv_igemm_kernel<T, WM, WN, WK, KT, OUT_MODE, NSTAGE>
-//   512 threads = 4 CONSUMER waves + 4 PRODUCER waves (wave specialisation).
+//   (NCW + 4) waves = NCW CONSUMER waves (4 or 8) + 4 PRODUCER waves (wave specialisation).
 //   Measured on the previous all-waves-do-everything kernel (profiles/r01_v3_ablation_128x128.json):
 //   LDS-DMA issue, LDS fragment reads and MFMAs serialise inside an in-order wave
 //   (B=64 l3.0.ds: DMA alone 452 us, MFMA + reads alone 511 us, together 754 us).  Here the
 //   producers only gather addresses and issue the LDS-DMA, the consumers only read fragments and
 //   issue MFMAs, so a producer stalled on the memory pipe never blocks the matrix pipe.
 //
-//   Consumers are arranged WM x WN x WK (WM*WN*WK == 4); EVERY consumer owns a 64x64 accumulator
+//   Consumers are arranged WM x WN x WK (WM*WN*WK == 4 or 8); EVERY consumer owns a 64x64 accumulator
 //   tile (2x2 MFMA 32x32 fragments), so the LDS->register traffic per MFMA is the same for all
 //   workgroup shapes (4 ds_read_b128 per 4 MFMAs).  Workgroup tile = 64*WM x 64*WN; when WK > 1
 //   the consumers of a K-group split the k-steps of every K tile between them and the partial
@@ -114,15 +114,22 @@ template <int SPR> __device__ __forceinline__ int swz(int row) {
 //     consumer: barrier(kt) ; read fragments of tile kt / MFMA (its reads of tile kt are all
 //               consumed by MFMAs before it reaches barrier(kt+1))
 // ---------------------------------------------------------------------------------------------
-template <int STAGE_BYTES, int NSTAGE, int EPI> struct WgPerCu {
+template <int STAGE_BYTES, int NSTAGE, int EPI, int NWAVES> struct WgPerCu {
     static constexpr int lds = CMax<STAGE_BYTES * NSTAGE, EPI>::v;
-    static constexpr int v = (160 * 1024 / lds) >= 2 ? 2 : 1;     // workgroups per CU the LDS admits (cap 2)
+    static constexpr int wgs = (160 * 1024 / lds) >= 2 ? 2 : 1;   // workgroups per CU the LDS admits (cap 2)
+    static constexpr int waves_per_simd = wgs * NWAVES / 4;
 };
+#define SMK_NCW (WM * WN * WK)
+#define SMK_EPI (SMK_NCW * 64 * (OUT_MODE == OUT_NCHW_F32 ? 65 : 68) * 4)
 
-template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
-__global__ __launch_bounds__(512, (2 * WgPerCu<64 * (WM + WN) * KT, NSTAGE, 4 * 64 * (OUT_MODE == OUT_NCHW_F32 ? 65 : 68) * 4>::v))
+// ABL (measurement only, results are garbage when != 0): 1 no MFMA, 2 no LDS-DMA after the prologue,
+// 3 no fragment reads in the loop, 4 LDS-DMA only (1+3)
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE, int ABL = 0>
+__global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
 void conv_igemm_kernel(const ConvParams p) {
-    static_assert(WM * WN * WK == 4, "four consumer waves per workgroup");
+    constexpr int NCW = SMK_NCW;               // consumer waves (4 or 8); 4 producer waves follow
+    constexpr int NT = (NCW + 4) * 64;
+    static_assert(NCW == 4 || NCW == 8, "four or eight consumer waves per workgroup");
     typedef Traits<T> TR;
     typedef typename TR::frag_t frag_t;
     constexpr int VE = TR::VE;
@@ -137,7 +144,7 @@ void conv_igemm_kernel(const ConvParams p) {
     static_assert(AHEAD >= 1 && AHEAD <= 3, "ring depth 2..4");
     constexpr int STAGE_BYTES = (BM + BN) * KT;
     constexpr int LDE = OUT_MODE == OUT_NCHW_F32 ? 65 : 68;
-    constexpr int EPI_BYTES = 4 * 64 * LDE * 4;                 // four 64x64 f32 accumulator tiles
+    constexpr int EPI_BYTES = NCW * 64 * LDE * 4;               // one 64x64 f32 accumulator tile per consumer
     constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -170,9 +177,10 @@ void conv_igemm_kernel(const ConvParams p) {
 
     floatx16 acc[2][2];                // consumers only
 
-    if (wave >= 4) {
+    if (wave >= NCW) {
         // =========================== PRODUCER: gather + LDS-DMA ===============================
-        const int ptid = tid - 256, pw = wave - 4;
+        const int ptid = tid - NCW * 64, pw = wave - NCW;
+        if (p.prio == -1) __builtin_amdgcn_s_setprio(1);    // (measurement: producers prioritised instead)
         const int cin_off = p.cin_off + g * p.g_cin_off;
         const T *wgt = (const T *)p.wgt + (size_t)g * p.g_wgt_off * p.Kpad;
         // LDS-DMA writes lane-linear: thread ptid fills (row ptid/SPR [+RPR*i], physical slot
@@ -266,10 +274,10 @@ void conv_igemm_kernel(const ConvParams p) {
             // tile kt: my pieces have landed; tiles kt+1 .. min(kt+AHEAD-1, nk-1) may still be in flight
             int younger = nk - 1 - kt;
             if (younger > AHEAD - 1) younger = AHEAD - 1;
-            wait_tiles<NP>(younger);
+            if (ABL == 2) wait_vmcnt<0>(); else wait_tiles<NP>(younger);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + AHEAD < nk) {
+            if (kt + AHEAD < nk && ABL != 2) {
                 set_tile(kt + AHEAD);
                 issue_tile(kt + AHEAD, islot);
             }
@@ -300,9 +308,19 @@ void conv_igemm_kernel(const ConvParams p) {
         // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
         auto mma_part = [&](int par, int q0, int q1) {
 #pragma unroll
-            for (int q = q0; q < q1; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+            for (int q = q0; q < q1; ++q) {
+                if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(fa[par][q >> 1]), "v"(fb[par][q & 1]));
+                else TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+            }
+        };
+        auto loop_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
+            if constexpr (ABL != 3 && ABL != 4) read_frags(buf, s, a, b);
         };
 
+        // matrix-pipe waves outrank the memory-issuing producers of the same SIMD (static priority)
+        if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
         __builtin_amdgcn_s_barrier();                      // barrier(0): tile 0 is complete
         asm volatile("" ::: "memory");
         read_frags(0, 0, fa[0], fb[0]);
@@ -323,12 +341,12 @@ void conv_igemm_kernel(const ConvParams p) {
                     // (hipcc waits lgkmcnt(0) at the loop head: keep the new reads behind MFMA 0)
                     mma_part(0, 0, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    read_frags(cur, 1, fa[1], fb[1]);
+                    loop_frags(cur, 1, fa[1], fb[1]);
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(0, 1, 4);
                     __builtin_amdgcn_sched_barrier(0);
                 } else if (s + 1 < NKS) {
-                    read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(s & 1, 0, 4);
                     __builtin_amdgcn_sched_barrier(0);
@@ -340,7 +358,7 @@ void conv_igemm_kernel(const ConvParams p) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();          // barrier(kt+1)
                         asm volatile("" ::: "memory");
-                        read_frags(nxt, 0, fa[0], fb[0]);
+                        loop_frags(nxt, 0, fa[0], fb[0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(s & 1, 2, 4);
@@ -353,7 +371,7 @@ void conv_igemm_kernel(const ConvParams p) {
 
     // ---- epilogue: the four accumulator tiles -> LDS -> (sum over the K-group) -> fused
     //      bias/res/relu -> global, by all eight waves ----------------------------------------
-    if (wave < 4) {
+    if (wave < NCW) {
         float *e = (float *)smem + wave * (64 * LDE);
         const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
@@ -372,7 +390,7 @@ void conv_igemm_kernel(const ConvParams p) {
     // region of consumer (wm, wn, wk): ((wm*WN + wn)*WK + wk) * 64*LDE floats
     if (OUT_MODE == OUT_NHWC) {
         constexpr int LPR = BN / 4;          // threads per output row (4 channels each)
-        constexpr int RPP = 512 / LPR;       // rows per pass
+        constexpr int RPP = NT / LPR;        // rows per pass
         const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
         const int n = n0 + c4;
         if (n < p.Nst) {
@@ -380,9 +398,8 @@ void conv_igemm_kernel(const ConvParams p) {
             T *out = (T *)p.out;
             const T *res = (const T *)p.res;
             const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
-#pragma unroll 4
-            for (int pass = 0; pass < BM / RPP; ++pass) {
-                const int row = pass * RPP + r0;
+#pragma unroll 2
+            for (int row = r0; row < BM; row += RPP) {
                 const int m = m0 + row;
                 if (m < p.M) {
                     const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
@@ -405,7 +422,7 @@ void conv_igemm_kernel(const ConvParams p) {
         }
     } else {
         // NCHW f32: threads run along m (contiguous positions of one channel plane)
-        constexpr int CG = 512 / BM;         // column groups processed concurrently
+        constexpr int CG = NT / BM;          // column groups processed concurrently
         const int row = tid % BM, cg = tid / BM;
         const int m = m0 + row;
         if (m < p.M) {
@@ -481,46 +498,54 @@ __global__ void conv_naive_kernel(const ConvParams p) {
 }
 
 // ---- dispatch ------------------------------------------------------------------------------
-static int g_num_cu = 256;
 Tuning g_tune;
 
 // Tile configurations: (BM, BN) in {128,64}^2, K tile 128 or 256 bytes, ring depth 2..4.
 // 64x64 tiles split K four ways inside the workgroup and therefore need the 256-byte K tile
 // (two k-steps per wave per tile).
 static int default_kt(int bm, int bn) { return (bm == 64 && bn == 64) ? 256 : 128; }
+// 256x128 tiles run eight consumer waves (4x2), 128-byte K tiles only
 static int default_stages(int bm, int bn, int kt) {
-    const int stage_bytes = (bm + bn) * kt;
-    if (stage_bytes >= 48 * 1024) return 2;
-    return 3;
+    if (bm == 128 && bn == 128 && kt == 128) return 2;       // 70 KB with the epilogue: two workgroups per CU
+    return (bm + bn) * kt * 3 <= 160 * 1024 ? 3 : 2;
 }
 
+// Tile choice, fitted to the per-layer micro-benchmark (profiles/r01_v4_convbench_b{1,8,64}_f16.json):
+// the largest tile whose grid still covers the chip about twice (two workgroups per CU hide each
+// other's hand-over bubbles), because the bytes staged through LDS per flop fall with the tile
+// area and the global->LDS path (~20-25 B/clk/CU beside running MFMAs) is what bounds the loop.
 TileChoice choose_tile(const ConvParams &p, int dtype) {
     (void)dtype;
     TileChoice t;
     if (g_tune.force_tile) {
-        static const int tb[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+        static const int tb[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
         t.bm = tb[g_tune.force_tile][0];
         t.bn = tb[g_tune.force_tile][1];
+        t.stages = default_stages(t.bm, t.bn, default_kt(t.bm, t.bn));
     } else {
-        auto blocks = [&](int bm, int bn) {
-            return (long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * (p.groups > 0 ? p.groups : 1);
+        const long ng = p.groups > 0 ? p.groups : 1;
+        auto tiles = [&](int bm, int bn) {
+            return (long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * ng * 16 / g_tune.min_blocks_x16;
         };
-        t.bn = p.Nst > 64 ? 128 : 64;
-        t.bm = p.M > 64 ? 128 : 64;
-        // keep every CU busy: shrink the tile while the grid is smaller than the chip
-        const long want = (long)g_num_cu * g_tune.min_blocks_x16 / 16;
-        if (blocks(t.bm, t.bn) < want && t.bm == 128) t.bm = 64;
-        if (blocks(t.bm, t.bn) < want && t.bn == 128) t.bn = 64;
+        if (p.Nst <= 64) {
+            if (tiles(128, 64) >= 200) { t.bm = 128; t.bn = 64; t.stages = 3; }
+            else { t.bm = 64; t.bn = 64; t.stages = 3; }
+        } else if (tiles(256, 128) >= 480 && p.K >= 1024) { t.bm = 256; t.bn = 128; t.stages = 3; }
+        else if (tiles(128, 128) >= 400) { t.bm = 128; t.bn = 128; t.stages = 2; }
+        else if (tiles(64, 128) >= 200) { t.bm = 64; t.bn = 128; t.stages = 3; }
+        else { t.bm = 64; t.bn = 64; t.stages = 3; }
     }
     t.kt = g_tune.kt ? g_tune.kt : default_kt(t.bm, t.bn);
     if (t.bm == 64 && t.bn == 64) t.kt = 256;
-    t.stages = g_tune.stages ? g_tune.stages : default_stages(t.bm, t.bn, t.kt);
+    if (t.bm == 256) t.kt = 128;
+    if (g_tune.stages) t.stages = g_tune.stages;
     return t;
 }
 
 template <typename T, int WM, int WN, int WK, int KT, int OM>
 static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int NTHREADS = (WM * WN * WK + 4) * 64;
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Nst + BN - 1) / BN;
     dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
     constexpr int STAGE_BYTES = (BM + BN) * KT;
@@ -530,23 +555,39 @@ static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
     if (stages < 2) stages = 2;
     if constexpr (MAXST >= 4) {
         if (stages == 4) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(512), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(NTHREADS), 0, s, p);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
     if constexpr (MAXST >= 3) {
         if (stages == 3) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(512), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(NTHREADS), 0, s, p);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(NTHREADS), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <typename T, int OM>
 static int launch_tiles(const ConvParams &p, TileChoice t, hipStream_t s) {
     const bool k256 = t.kt == 256;
+    if constexpr (sizeof(T) == 2 && OM == OUT_NHWC) {
+        if (g_tune.ablate && !k256 && t.bn == 128 && t.bm >= 128) {
+            const int tilesM = (p.M + t.bm - 1) / t.bm, tilesN = (p.Nst + 127) / 128;
+            dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
+#define SMK_ABL(A)                                                                                                      \
+    if (g_tune.ablate == A) {                                                                                           \
+        if (t.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 4, 2, 1, 128, OM, 3, A>), grid, dim3(768), 0, s, p);  \
+        else if (t.stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 2, A>), grid, dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 3, A>), grid, dim3(512), 0, s, p);              \
+        return hipGetLastError() == hipSuccess ? 0 : -4;                                                               \
+    }
+            SMK_ABL(1) SMK_ABL(2) SMK_ABL(3) SMK_ABL(4)
+#undef SMK_ABL
+        }
+    }
+    if (t.bm == 256) return launch_stages<T, 4, 2, 1, 128, OM>(p, t.stages, s);
     if (t.bm == 128 && t.bn == 128)
         return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(p, t.stages, s);
     if (t.bm == 128 && t.bn == 64)

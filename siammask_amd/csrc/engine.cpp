@@ -488,6 +488,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
             return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
     }
     p.xcd_mode = g_tune.xcd_mode;
+    p.prio = g_tune.prio;
     p.ci_shift = -1;
     for (int sh = 0; sh < 16; ++sh)
         if ((1 << sh) == p.Ci) p.ci_shift = sh;
@@ -508,15 +509,16 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
 // (0 auto, 1 128 B, 2 256 B), bits 6-7 ring depth (0 auto, 1..3 -> 2..4 stages)
 static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
     TileChoice t = choose_tile(p, dtype);
-    static const int tb[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int tb[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
     const int tile = code & 15, kt = (code >> 4) & 3, st = (code >> 6) & 3;
-    if (tile >= 1 && tile <= 4) {
+    if (tile >= 1 && tile <= 5) {
         t.bm = tb[tile][0]; t.bn = tb[tile][1];
         t.kt = (t.bm == 64 && t.bn == 64) ? 256 : 128;
-        t.stages = ((t.bm + t.bn) * t.kt >= 48 * 1024) ? 2 : 3;
+        t.stages = (t.bm == 128 && t.bn == 128) ? 2 : 3;
     }
     if (kt) t.kt = kt == 2 ? 256 : 128;
     if (t.bm == 64 && t.bn == 64) t.kt = 256;
+    if (t.bm == 256) t.kt = 128;
     if (st) t.stages = st + 1;
     return t;
 }
@@ -932,10 +934,11 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
 int smk_tune(const char *key, int value) {
     if (!key) return fail(SMK_E_ARG, "smk_tune: key is NULL");
     if (!strcmp(key, "xcd_mode")) g_tune.xcd_mode = value;
-    else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 4) return fail(SMK_E_ARG, "force_tile 0..4"); g_tune.force_tile = value; }
+    else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "force_tile 0..5"); g_tune.force_tile = value; }
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
+    else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "ablate")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "ablate 0..5"); g_tune.ablate = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);

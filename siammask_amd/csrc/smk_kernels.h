@@ -53,6 +53,7 @@ struct ConvParams {
     int xcd_mode;          // 0: tiles in launch order, 1: XCD-contiguous tm-major, 2: tn-major
     int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
+    int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
 };
 
 // run-time tuning knobs (smk_tune): measured defaults, overridable for A/B runs
@@ -62,6 +63,7 @@ struct Tuning {
     int min_blocks_x16 = 16;   // shrink tiles while grid < CUs * min_blocks_x16/16
     int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2..4
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
+    int prio = 0;              // consumer-wave priority (see ConvParams::prio)
     int ablate = 0;            // measurement only: ablated variants of the 128x128x128 kernel (see conv_igemm.hip)
 };
 extern Tuning g_tune;

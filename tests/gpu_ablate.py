@@ -12,16 +12,16 @@ from siammask_amd import _lib, ops  # noqa: E402
 
 SHAPES = {"l3.0.ds": (512, 31, 1024, 3, 1, 1, 1), "l3.c2": (256, 31, 256, 3, 1, 2, 2), "l3.c3": (256, 31, 1024, 1, 1, 0, 1)}
 out = {}
-for B in (4, 8, 16, 64):
+for B in (8, 64):
     for name, (cin, hw, cout, k, st, pad, dil) in SHAPES.items():
-        for stages in (2, 3):
+        for tile, stages in (((128, 128), 2), ((128, 128), 3), ((256, 128), 3)):
             row = {}
-            for abl in range(6):
+            for abl in range(5):
                 _lib.tune(ablate=abl)
-                row[abl] = round(ops.bench_conv(B, cin, hw, hw, cout, k, st, pad, dil, tile=(128, 128), kt=128,
+                row[abl] = round(ops.bench_conv(B, cin, hw, hw, cout, k, st, pad, dil, tile=tile, kt=128,
                                                 stages=stages, iters=20), 2)
             _lib.tune(ablate=0)
-            out["B%d %s s%d" % (B, name, stages)] = row
-            print("B=%-3d %-8s s%d  full %8.2f | noMFMA %8.2f | noDMA %8.2f | noDSread %8.2f | DMAonly %8.2f | noWdma %8.2f" % (
-                B, name, stages, row[0], row[1], row[2], row[3], row[4], row[5]), flush=True)
+            out["B%d %s %dx%d s%d" % (B, name, tile[0], tile[1], stages)] = row
+            print("B=%-3d %-8s %dx%d s%d  full %8.2f | noMFMA %8.2f | noDMA %8.2f | noDSread %8.2f | DMAonly %8.2f" % (
+                B, name, tile[0], tile[1], stages, row[0], row[1], row[2], row[3], row[4]), flush=True)
 json.dump(out, open("gpurun_out/ablate.json", "w"), indent=1)

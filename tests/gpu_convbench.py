@@ -48,7 +48,7 @@ LAYERS = {
     "v0.2":        (16, 61, 4, 3, 1, 1, 1, 1, 0, None, 0, 0, 1),
 }
 CONFIGS = [((128, 128), 128), ((128, 128), 256), ((128, 64), 128), ((128, 64), 256),
-           ((64, 128), 128), ((64, 128), 256), ((64, 64), 256)]
+           ((64, 128), 128), ((64, 128), 256), ((64, 64), 256), ((256, 128), 128)]
 
 
 def main():

@@ -59,7 +59,7 @@ def test_conv_classes(cfg, dtype):
         errs[algo] = rel_err(y, ref)
     # every instantiation of the kernel: workgroup tile x K-tile bytes x LDS ring depth x epilogue
     for tile, kt in (((128, 128), 128), ((128, 128), 256), ((128, 64), 128), ((128, 64), 256),
-                     ((64, 128), 128), ((64, 128), 256), ((64, 64), 256)):
+                     ((64, 128), 128), ((64, 128), 256), ((64, 64), 256), ((256, 128), 128)):
         for stages in (2, 3, 4):
             for algo in ("mfma", "mfma_nchw"):
                 y = ops.conv2d(xd, w, b, stride, pad, dil, dtype=dtype, algo=algo, tile=tile, kt=kt,
@@ -80,7 +80,7 @@ def test_conv_epilogues(dtype):
     base = O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64))
     xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
     for algo, tile in (("naive", None), ("mfma", None), ("mfma", (128, 128)), ("mfma", (128, 64)),
-                       ("mfma", (64, 128)), ("mfma", (64, 64))):
+                       ("mfma", (64, 128)), ("mfma", (64, 64)), ("mfma", (256, 128))):
         y = ops.conv2d(xd, w, b, relu=True, dtype=dtype, algo=algo, tile=tile).cpu().numpy()
         assert rel_err(y, np.maximum(base, 0)) <= TOL[dtype], (algo, tile)
         y = ops.conv2d(xd, w, b, relu=True, res=rd, res_mode=1, dtype=dtype, algo=algo, tile=tile).cpu().numpy()
@@ -133,7 +133,7 @@ def test_heavy_real_shapes(dtype):
         ref = O.conv2d(_q(x, dtype), _q(w, dtype), None, 1, pad, dil)
         xd = torch.from_numpy(x).cuda()
         for tile, kt, stages in ((None, 0, 0), ((128, 128), 128, 2), ((128, 128), 128, 4), ((128, 64), 256, 3),
-                                 ((64, 128), 128, 4), ((64, 64), 256, 2), ((64, 64), 256, 4)):
+                                 ((64, 128), 128, 4), ((64, 64), 256, 2), ((64, 64), 256, 4), ((256, 128), 128, 3)):
             y = ops.conv2d(xd, w, pad=pad, dil=dil, dtype=dtype, tile=tile, kt=kt, stages=stages).cpu().numpy()
             assert rel_err(y, ref) <= TOL[dtype], (cin, tile, kt, stages)
 
