@@ -84,8 +84,9 @@ class Workload(object):
         m = self.model
         x = self.xs[i % len(self.xs)]
         if self.fused:
-            o = m.track_step(x, self.twh, refine=self.refine)
-            self.last = (o["cls"], o["loc"], o["mask"], o["refine"])
+            # inputs are pre-staged persistent buffers: read in place (no staging copy per frame)
+            o = m.track_step(x, self.twh, refine=self.refine, stage=False)
+            self.last = (o["box"], o["loc"], o["mask"], o["refine"])
         elif self.variant == "rpn":
             cls, loc = m.track(x)
             self.last = (cls, loc, None, None)
@@ -117,7 +118,10 @@ def timed_run(w, steps, warmup, world, gather):
     res_masks = res_box = None
     if w.refine:
         res_masks = torch.empty((w.B, steps, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev)
-    res_box = torch.empty((w.B, steps, 30 * 625), dtype=torch.float16, device=dev)
+    # per stream and frame: the decoded box (cx, cy, w, h, score, penalty, pscore, best_id) and the
+    # 127x127 refine mask logits -- the fixed-size results a tracker keeps (tools/test.py:296-311)
+    res_box = torch.empty((w.B, steps, 8 if w.fused else 30 * 625), dtype=torch.float32 if w.fused else torch.float16,
+                          device=dev)
     for i in range(warmup):
         w.step(i)
     torch.cuda.synchronize(dev)
@@ -128,8 +132,11 @@ def timed_run(w, steps, warmup, world, gather):
     for i in range(steps):
         cls, loc, mask, ref = w.step(i)
         # results kept for the end-of-batch gather (scores/boxes + mask logits)
-        res_box[:, i, :10 * 625].copy_(cls.reshape(w.B, -1))
-        res_box[:, i, 10 * 625:].copy_(loc.reshape(w.B, -1))
+        if w.fused:
+            res_box[:, i].copy_(cls)                  # `cls` slot carries the decoded box [B,8]
+        else:
+            res_box[:, i, :10 * 625].copy_(cls.reshape(w.B, -1))
+            res_box[:, i, 10 * 625:].copy_(loc.reshape(w.B, -1))
         if ref is not None:
             res_masks[:, i].copy_(ref)
     if world > 1:

@@ -122,11 +122,17 @@ template <int STAGE_BYTES, int NSTAGE, int EPI, int NWAVES> struct WgPerCu {
 #define SMK_NCW (WM * WN * WK)
 #define SMK_EPI (SMK_NCW * 64 * (OUT_MODE == OUT_NCHW_F32 ? 65 : 68) * 4)
 
-// ABL (measurement only, results are garbage when != 0): 1 no MFMA, 2 no LDS-DMA after the prologue,
-// 3 no fragment reads in the loop, 4 LDS-DMA only (1+3)
-template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE, int ABL = 0>
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
 __global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
-void conv_igemm_kernel(const ConvParams p) {
+void conv_igemm_kernel(const ConvBatch cb) {
+    // several independent convolutions can share one launch (same instantiation): workgroups
+    // [start[i], start[i+1]) belong to problem i
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CONV_BATCH_MAX; ++i)
+        if (i < cb.n && (int)blockIdx.x >= cb.start[i]) pi = i;
+    const ConvParams &p = cb.p[pi];
+    const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
     constexpr int NCW = SMK_NCW;               // consumer waves (4 or 8); 4 producer waves follow
     constexpr int NT = (NCW + 4) * 64;
     static_assert(NCW == 4 || NCW == 8, "four or eight consumer waves per workgroup");
@@ -159,9 +165,9 @@ void conv_igemm_kernel(const ConvParams p) {
     // tile sequence, so the workgroups sharing one activation row panel (same tm, all tn) run
     // on ONE XCD and that panel is fetched into one L2 only.
     const int tilesN = (p.Nst + BN - 1) / BN;
-    int t = blockIdx.x;
+    int t = (int)blockIdx.x - wg_first;
     if (p.xcd_mode != 0) {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int nblk = wg_count, q = nblk >> 3, r = nblk & 7;
         const int x = t & 7, j = t >> 3;
         t = x * q + (x < r ? x : r) + j;
     }
@@ -274,10 +280,10 @@ void conv_igemm_kernel(const ConvParams p) {
             // tile kt: my pieces have landed; tiles kt+1 .. min(kt+AHEAD-1, nk-1) may still be in flight
             int younger = nk - 1 - kt;
             if (younger > AHEAD - 1) younger = AHEAD - 1;
-            if (ABL == 2) wait_vmcnt<0>(); else wait_tiles<NP>(younger);
+            wait_tiles<NP>(younger);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + AHEAD < nk && ABL != 2) {
+            if (kt + AHEAD < nk) {
                 set_tile(kt + AHEAD);
                 issue_tile(kt + AHEAD, islot);
             }
@@ -308,13 +314,7 @@ void conv_igemm_kernel(const ConvParams p) {
         // the four MFMAs of a k-step, issued as [q0, q1) so that other work can be placed between them
         auto mma_part = [&](int par, int q0, int q1) {
 #pragma unroll
-            for (int q = q0; q < q1; ++q) {
-                if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(fa[par][q >> 1]), "v"(fb[par][q & 1]));
-                else TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
-            }
-        };
-        auto loop_frags = [&](int buf, int s, frag_t (&a)[2], frag_t (&b)[2]) {
-            if constexpr (ABL != 3 && ABL != 4) read_frags(buf, s, a, b);
+            for (int q = q0; q < q1; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
         };
 
         // matrix-pipe waves outrank the memory-issuing producers of the same SIMD (static priority)
@@ -341,12 +341,12 @@ void conv_igemm_kernel(const ConvParams p) {
                     // (hipcc waits lgkmcnt(0) at the loop head: keep the new reads behind MFMA 0)
                     mma_part(0, 0, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    loop_frags(cur, 1, fa[1], fb[1]);
+                    read_frags(cur, 1, fa[1], fb[1]);
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(0, 1, 4);
                     __builtin_amdgcn_sched_barrier(0);
                 } else if (s + 1 < NKS) {
-                    loop_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    read_frags(cur, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(s & 1, 0, 4);
                     __builtin_amdgcn_sched_barrier(0);
@@ -358,7 +358,7 @@ void conv_igemm_kernel(const ConvParams p) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();          // barrier(kt+1)
                         asm volatile("" ::: "memory");
-                        loop_frags(nxt, 0, fa[0], fb[0]);
+                        read_frags(nxt, 0, fa[0], fb[0]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(s & 1, 2, 4);
@@ -369,8 +369,26 @@ void conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
 
-    // ---- epilogue: the four accumulator tiles -> LDS -> (sum over the K-group) -> fused
-    //      bias/res/relu -> global, by all eight waves ----------------------------------------
+    // ---- epilogue: the accumulator tiles -> LDS -> (sum over the K-group) -> fused
+    //      bias/res/relu -> global, by all waves.  The residual rows are fetched first, so that
+    //      their latency hides behind the accumulator hand-over through LDS. ----------------------
+    constexpr int LPR = BN / 4;                          // NHWC: threads per output row (4 channels each)
+    constexpr int RPP = NT / LPR;                        // rows per pass
+    constexpr int NPASS = (BM + RPP - 1) / RPP;
+    const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
+    floatx4 rv[NPASS];
+    if (OUT_MODE == OUT_NHWC) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) rv[ps] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (p.res_mode != RES_NONE && n0 + c4 < p.Nst) {
+            const T *res = (const T *)p.res;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = ps * RPP + r0, m = m0 + row;
+                if (row < BM && m < p.M) rv[ps] = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n0 + c4);
+            }
+        }
+    }
     if (wave < NCW) {
         float *e = (float *)smem + wave * (64 * LDE);
         const int frow = lane & 31, fhalf = lane >> 5;
@@ -389,39 +407,34 @@ void conv_igemm_kernel(const ConvParams p) {
     const float *ebase = (const float *)smem;
     // region of consumer (wm, wn, wk): ((wm*WN + wn)*WK + wk) * 64*LDE floats
     if (OUT_MODE == OUT_NHWC) {
-        constexpr int LPR = BN / 4;          // threads per output row (4 channels each)
-        constexpr int RPP = NT / LPR;        // rows per pass
-        const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
         const int n = n0 + c4;
         if (n < p.Nst) {
             const floatx4 bv = *(const floatx4 *)(bias + n);
             T *out = (T *)p.out;
-            const T *res = (const T *)p.res;
             const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
-#pragma unroll 2
-            for (int row = r0; row < BM; row += RPP) {
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = ps * RPP + r0;
                 const int m = m0 + row;
-                if (m < p.M) {
+                if (row < BM && m < p.M) {
                     const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
                     floatx4 v = *(const floatx4 *)er;
 #pragma unroll
                     for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(er + q * (64 * LDE));
                     v += bv;
-                    floatx4 rv = {0.f, 0.f, 0.f, 0.f};
-                    if (p.res_mode != RES_NONE)
-                        rv = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n);
-                    if (p.res_mode == RES_PRE_RELU) v += rv;
+                    if (p.res_mode == RES_PRE_RELU) v += rv[ps];
                     if (p.relu) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                     }
-                    if (p.res_mode == RES_POST_RELU) v += rv;
+                    if (p.res_mode == RES_POST_RELU) v += rv[ps];
                     TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
                 }
             }
         }
     } else {
-        // NCHW f32: threads run along m (contiguous positions of one channel plane)
+        // NCHW f32: threads run along m (contiguous positions of one channel plane); the tensor is
+        // handed to the caller and not re-read on the device: streaming (non-temporal) stores
         constexpr int CG = NT / BM;          // column groups processed concurrently
         const int row = tid % BM, cg = tid / BM;
         const int m = m0 + row;
@@ -430,6 +443,7 @@ void conv_igemm_kernel(const ConvParams p) {
             const int b = m / hw, pos = m - b * hw;
             float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
             const float *er = ebase + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
+#pragma unroll 4
             for (int j = cg; j < BN; j += CG) {
                 const int n = n0 + j;
                 if (n < p.N) {
@@ -439,7 +453,8 @@ void conv_igemm_kernel(const ConvParams p) {
                     for (int q = 1; q < WK; ++q) v += ec[q * (64 * LDE)];
                     v += bias[n];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    obase[(size_t)n * hw] = v;
+                    if (p.nt_store) __builtin_nontemporal_store(v, obase + (size_t)n * hw);
+                    else obase[(size_t)n * hw] = v;
                 }
             }
         }
@@ -543,11 +558,18 @@ TileChoice choose_tile(const ConvParams &p, int dtype) {
 }
 
 template <typename T, int WM, int WN, int WK, int KT, int OM>
-static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
+static int launch_stages(ConvBatch &cb, int stages, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = (WM * WN * WK + 4) * 64;
-    const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.Nst + BN - 1) / BN;
-    dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
+    int total = 0, groups = 1;
+    for (int i = 0; i < cb.n; ++i) {
+        const ConvParams &p = cb.p[i];
+        cb.start[i] = total;
+        total += ((p.M + BM - 1) / BM) * ((p.Nst + BN - 1) / BN);
+        if (p.groups > groups) groups = p.groups;
+    }
+    for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
+    dim3 grid(total, 1, groups);
     constexpr int STAGE_BYTES = (BM + BN) * KT;
     constexpr int MAXST = 160 * 1024 / STAGE_BYTES;      // deepest ring that fits the 160 KB LDS
     if (stages > MAXST) stages = MAXST;
@@ -555,56 +577,50 @@ static int launch_stages(const ConvParams &p, int stages, hipStream_t s) {
     if (stages < 2) stages = 2;
     if constexpr (MAXST >= 4) {
         if (stages == 4) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(NTHREADS), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 4>), grid, dim3(NTHREADS), 0, s, cb);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
     if constexpr (MAXST >= 3) {
         if (stages == 3) {
-            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(NTHREADS), 0, s, p);
+            hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 3>), grid, dim3(NTHREADS), 0, s, cb);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN, WK, KT, OM, 2>), grid, dim3(NTHREADS), 0, s, cb);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <typename T, int OM>
-static int launch_tiles(const ConvParams &p, TileChoice t, hipStream_t s) {
+static int launch_tiles(ConvBatch &cb, TileChoice t, hipStream_t s) {
     const bool k256 = t.kt == 256;
-    if constexpr (sizeof(T) == 2 && OM == OUT_NHWC) {
-        if (g_tune.ablate && !k256 && t.bn == 128 && t.bm >= 128) {
-            const int tilesM = (p.M + t.bm - 1) / t.bm, tilesN = (p.Nst + 127) / 128;
-            dim3 grid(tilesM * tilesN, 1, p.groups > 0 ? p.groups : 1);
-#define SMK_ABL(A)                                                                                                      \
-    if (g_tune.ablate == A) {                                                                                           \
-        if (t.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<T, 4, 2, 1, 128, OM, 3, A>), grid, dim3(768), 0, s, p);  \
-        else if (t.stages == 2) hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 2, A>), grid, dim3(512), 0, s, p); \
-        else hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 1, 128, OM, 3, A>), grid, dim3(512), 0, s, p);              \
-        return hipGetLastError() == hipSuccess ? 0 : -4;                                                               \
-    }
-            SMK_ABL(1) SMK_ABL(2) SMK_ABL(3) SMK_ABL(4)
-#undef SMK_ABL
-        }
-    }
-    if (t.bm == 256) return launch_stages<T, 4, 2, 1, 128, OM>(p, t.stages, s);
+    if (t.bm == 256) return launch_stages<T, 4, 2, 1, 128, OM>(cb, t.stages, s);
     if (t.bm == 128 && t.bn == 128)
-        return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(p, t.stages, s);
+        return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(cb, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(cb, t.stages, s);
     if (t.bm == 128 && t.bn == 64)
-        return k256 ? launch_stages<T, 2, 1, 2, 256, OM>(p, t.stages, s) : launch_stages<T, 2, 1, 2, 128, OM>(p, t.stages, s);
+        return k256 ? launch_stages<T, 2, 1, 2, 256, OM>(cb, t.stages, s) : launch_stages<T, 2, 1, 2, 128, OM>(cb, t.stages, s);
     if (t.bm == 64 && t.bn == 128)
-        return k256 ? launch_stages<T, 1, 2, 2, 256, OM>(p, t.stages, s) : launch_stages<T, 1, 2, 2, 128, OM>(p, t.stages, s);
-    return launch_stages<T, 1, 1, 4, 256, OM>(p, t.stages, s);
+        return k256 ? launch_stages<T, 1, 2, 2, 256, OM>(cb, t.stages, s) : launch_stages<T, 1, 2, 2, 128, OM>(cb, t.stages, s);
+    return launch_stages<T, 1, 1, 4, 256, OM>(cb, t.stages, s);
+}
+
+// all problems of a batch share dtype, epilogue mode (NHWC / NCHW) and the tile configuration
+int launch_conv_mfma_batch(ConvBatch &cb, int dtype, TileChoice t, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (cb.n < 1 || cb.n > CONV_BATCH_MAX) return -1;
+    const int om = cb.p[0].out_mode;
+    for (int i = 1; i < cb.n; ++i)
+        if (cb.p[i].out_mode != om || (cb.p[i].groups > 1) != (cb.p[0].groups > 1)) return -1;
+    if (dtype == DT_F16)
+        return om == OUT_NHWC ? launch_tiles<_Float16, OUT_NHWC>(cb, t, s) : launch_tiles<_Float16, OUT_NCHW_F32>(cb, t, s);
+    return om == OUT_NHWC ? launch_tiles<float, OUT_NHWC>(cb, t, s) : launch_tiles<float, OUT_NCHW_F32>(cb, t, s);
 }
 
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == DT_F16) {
-        return p.out_mode == OUT_NHWC ? launch_tiles<_Float16, OUT_NHWC>(p, t, s)
-                                      : launch_tiles<_Float16, OUT_NCHW_F32>(p, t, s);
-    }
-    return p.out_mode == OUT_NHWC ? launch_tiles<float, OUT_NHWC>(p, t, s)
-                                  : launch_tiles<float, OUT_NCHW_F32>(p, t, s);
+    ConvBatch cb;
+    cb.n = 1;
+    cb.p[0] = p;
+    return launch_conv_mfma_batch(cb, dtype, t, stream);
 }
 
 int launch_conv_naive(const ConvParams &p, int dtype, void *stream) {

@@ -489,6 +489,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     }
     p.xcd_mode = g_tune.xcd_mode;
     p.prio = g_tune.prio;
+    p.nt_store = (g_tune.nt_store && o.nchw_out && (double)p.M * p.N * 4 >= 4.0e6) ? 1 : 0;
     p.ci_shift = -1;
     for (int sh = 0; sh < 16; ++sh)
         if ((1 << sh) == p.Ci) p.ci_shift = sh;
@@ -550,6 +551,29 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     return 0;
 }
 
+// several independent convolutions as ONE launch (same dtype / epilogue mode / tile for all):
+// removes launch boundaries and fills the chip when the single problems are small
+struct ConvJob { const char *id; const Act *in; const Act *out; ConvOpt o; };
+
+static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, int lead, hipStream_t s) {
+    if (jobs.empty() || (int)jobs.size() > CONV_BATCH_MAX) return fail(SMK_E_ARG, "internal: bad conv job count");
+    if (c->prof || jobs.size() == 1 || !g_tune.merge) {        // per-layer attribution while profiling
+        for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
+        return 0;
+    }
+    ConvBatch cb;
+    cb.n = (int)jobs.size();
+    for (int i = 0; i < cb.n; ++i) {
+        auto it = c->conv.find(jobs[i].id);
+        if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", jobs[i].id);
+        CHK(conv_params(c, it->second, *jobs[i].in, jobs[i].out, B, jobs[i].o, cb.p[i]));
+    }
+    const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], c->dtype);
+    if (launch_conv_mfma_batch(cb, c->dtype, t, s))
+        return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the network
 // ---------------------------------------------------------------------------------------------
@@ -594,19 +618,26 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             ConvOpt o2; o2.relu = 1; o2.stride = stride; o2.pad = pad2; o2.dil = dil;
             Act res = cur;
             const bool par = parallel_ok(c);
+            const std::string id_ds = id + "ds", id_c1 = id + "c1";
             if (b == 0) {
-                // the shortcut conv only depends on the block input: run it beside conv1->conv2
+                // the shortcut conv only depends on the block input: it shares a launch with conv1
                 Act r = act(c, "r", so, so, planes * 4);
                 ConvOpt od;
                 if (st == 0) { od.stride = 1; od.pad = 0; }          // 1x1
                 else if (st == 1) { od.stride = 2; od.pad = 0; }     // 3x3 s2 p0
                 else { od.stride = 1; od.pad = 1; }                  // 3x3 s1 p1
-                hipStream_t sd = par ? c->side[0] : s;
-                if (par) CHK(stream_dep(c, s, sd));
-                CHK(run_conv(c, (id + "ds").c_str(), cur, &r, B, od, sd));
+                if (par) {
+                    hipStream_t sd = c->side[0];
+                    CHK(stream_dep(c, s, sd));
+                    CHK(run_conv(c, id_ds.c_str(), cur, &r, B, od, sd));
+                    CHK(run_conv(c, id_c1.c_str(), cur, &t1, B, o1, s));
+                } else {
+                    CHK(run_conv_jobs(c, {{id_ds.c_str(), &cur, &r, od}, {id_c1.c_str(), &cur, &t1, o1}}, B, 0, s));
+                }
                 res = r;
+            } else {
+                CHK(run_conv(c, id_c1.c_str(), cur, &t1, B, o1, s));
             }
-            CHK(run_conv(c, (id + "c1").c_str(), cur, &t1, B, o1, s));
             CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
             if (b == 0 && par) CHK(stream_dep(c, c->side[0], s));
             const bool last = b == STAGE_BLOCKS[st] - 1;
@@ -669,9 +700,13 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     hipStream_t s_loc = par ? c->side[0] : s, s_cls = (par && want_mask) ? c->side[1] : s;
     if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
-    CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
     ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
-    CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
+    if (par) {
+        CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
+        CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
+    } else {
+        CHK(run_conv_jobs(c, {{"cls3", &h0, nullptr, oc}, {"loc3", &h0, nullptr, ol}}, B, 1, s));
+    }
     if (want_mask) {
         ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
         CHK(run_conv(c, "mask3", h0, nullptr, B, om, s));
@@ -711,15 +746,24 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     // deconv(corr_feature[:, :, y, x]) -> [15,15,32]            (:145,:149)
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
     ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
-    CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
+    Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
+    const bool merged = !par && !c->prof && g_tune.merge;
+    if (merged) {
+        // the window convs only depend on the kept backbone features and pos: one launch with deconv
+        w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
+        CHK(run_conv_jobs(c, {{"v2.0", &p2, &v2a, w2}, {"v1.0", &p1, &v1a, w1}, {"v0.0", &p0, &v0a, w0},
+                              {"deconv", &corr, &d1, od}}, B, 0, s));
+    } else {
+        CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
+    }
     Act d = act(c, "rf_d", 15, 15, 32);
     // stage 2 @15x15                                             (:150)
     Act h2a = act(c, "rf_h2a", 15, 15, 32), h2b = act(c, "rf_h2b", 15, 15, 32);
     CHK(run_conv(c, "h2.0", d, &h2a, B, r3, s));
     CHK(run_conv(c, "h2.2", h2a, &h2b, B, r3, s));
-    Act v2a = act(c, "rf_v2a", 15, 15, 128), s2 = act(c, "rf_s2", 15, 15, 32);
+    Act s2 = act(c, "rf_s2", 15, 15, 32);
     if (par) CHK(hipStreamWaitEvent(s, ev_v2, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v2"));
-    else CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
+    else if (!merged) CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
     ConvOpt a2 = r3; a2.res = &h2b; a2.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v2.2", v2a, &s2, B, a2, s));
     Act u0 = act(c, "rf_u0", 31, 31, 16);
@@ -729,9 +773,9 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     Act h1a = act(c, "rf_h1a", 31, 31, 16), h1b = act(c, "rf_h1b", 31, 31, 16);
     CHK(run_conv(c, "h1.0", u0, &h1a, B, r3, s));
     CHK(run_conv(c, "h1.2", h1a, &h1b, B, r3, s));
-    Act v1a = act(c, "rf_v1a", 31, 31, 64), s1 = act(c, "rf_s1", 31, 31, 16);
+    Act s1 = act(c, "rf_s1", 31, 31, 16);
     if (par) CHK(hipStreamWaitEvent(s, ev_v1, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v1"));
-    else CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
+    else if (!merged) CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
     ConvOpt a1 = r3; a1.res = &h1b; a1.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v1.2", v1a, &s1, B, a1, s));
     Act u1 = act(c, "rf_u1", 61, 61, 8);
@@ -741,9 +785,9 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     Act h0a = act(c, "rf_h0a", 61, 61, 8), h0b = act(c, "rf_h0b", 61, 61, 8);
     CHK(run_conv(c, "h0.0", u1, &h0a, B, r3, s));
     CHK(run_conv(c, "h0.2", h0a, &h0b, B, r3, s));
-    Act v0a = act(c, "rf_v0a", 61, 61, 16), s0 = act(c, "rf_s0", 61, 61, 8);
+    Act s0 = act(c, "rf_s0", 61, 61, 8);
     if (par) CHK(hipStreamWaitEvent(s, ev_v0, 0) == hipSuccess ? 0 : fail(SMK_E_HIP, "wait ev_v0"));
-    else CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
+    else if (!merged) CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
     ConvOpt a0 = r3; a0.res = &h0b; a0.res_mode = RES_POST_RELU;
     CHK(run_conv(c, "v0.2", v0a, &s0, B, a0, s));
     ConvOpt pu2; pu2.pad = 1; pu2.ups = true; pu2.Hl = pu2.Wl = 127; pu2.nchw_out = out;
@@ -938,8 +982,9 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
+    else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
-    else if (!strcmp(key, "ablate")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "ablate 0..5"); g_tune.ablate = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
     return 0;

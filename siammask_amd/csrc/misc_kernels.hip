@@ -249,7 +249,8 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
 // 3125 candidates; ties resolve to the lowest index like np.argmax.  Removes the device->host
 // round trip between track_mask and track_refine.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
+constexpr int DEC_THREADS = 1024;
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams p) {
     const int b = blockIdx.x, SS = p.S * p.S, n = p.A * SS;
     const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
     const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
@@ -275,12 +276,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
         const double ps = penalty * score * (1.0 - p.window_influence) + p.window[rem] * p.window_influence;
         if (ps > best || (ps == best && i < best_i)) { best = ps; best_i = i; }
     }
-    __shared__ double sv[256];
-    __shared__ int si[256];
+    __shared__ double sv[DEC_THREADS];
+    __shared__ int si[DEC_THREADS];
     sv[threadIdx.x] = best;
     si[threadIdx.x] = best_i;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = DEC_THREADS / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             const double v = sv[threadIdx.x + s];
             const int j = si[threadIdx.x + s];
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeParams p) {
 
 int launch_decode(const DecodeParams &p, void *stream) {
     if (p.A > 8 || p.B < 1) return -1;
-    hipLaunchKernelGGL(decode_kernel, dim3(p.B), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(decode_kernel, dim3(p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

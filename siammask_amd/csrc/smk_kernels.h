@@ -54,6 +54,15 @@ struct ConvParams {
     int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
+    int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
+};
+
+// several independent convolutions in one launch (same kernel instantiation for all of them)
+constexpr int CONV_BATCH_MAX = 4;
+struct ConvBatch {
+    int n;                                // problems in this launch
+    int start[CONV_BATCH_MAX + 1];        // first workgroup of problem i; start[n..] = grid size
+    ConvParams p[CONV_BATCH_MAX];
 };
 
 // run-time tuning knobs (smk_tune): measured defaults, overridable for A/B runs
@@ -64,7 +73,8 @@ struct Tuning {
     int stages = 0;            // LDS ring depth of the conv kernel: 0 auto, 2..4
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
     int prio = 0;              // consumer-wave priority (see ConvParams::prio)
-    int ablate = 0;            // measurement only: ablated variants of the 128x128x128 kernel (see conv_igemm.hip)
+    int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
+    int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
 };
 extern Tuning g_tune;
 
@@ -147,6 +157,7 @@ struct DecodeParams {
 struct TileChoice { int bm, bn, kt, stages; };
 TileChoice choose_tile(const ConvParams &p, int dtype);
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
+int launch_conv_mfma_batch(ConvBatch &cb, int dtype, TileChoice t, void *stream);
 int launch_conv_naive(const ConvParams &p, int dtype, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
