@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference call sequence (track_mask, track_refine(fixed pos)) instead of the "
                          "fused device-resident step")
+    ap.add_argument("--inputs", type=int, default=4, help="ring of distinct pre-staged search batches")
     ap.add_argument("--tune", default="", help="library tuning knobs, e.g. xcd_mode=0,force_tile=1")
     ap.add_argument("--profile-out", default="", help="write the per-layer launch profile (JSON) here")
     args = ap.parse_args()
@@ -256,7 +257,7 @@ def main():
     torch.cuda.set_device(dev)
     gather = sdist.ResultGather(dev)
 
-    w = Workload(args.workload, dev, rank, batch=args.batch, fused=not args.unfused)
+    w = Workload(args.workload, dev, rank, n_inputs=args.inputs, batch=args.batch, fused=not args.unfused)
     prewarm(w, args.prewarm_seconds)
     dt = timed_run(w, args.steps, args.warmup, world, gather)
     frames = w.B * world * args.steps

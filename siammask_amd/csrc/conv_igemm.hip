@@ -43,6 +43,16 @@ template <> struct Traits<float> {
     }
     static __device__ inline floatx4 load4(const float *p) { return *(const floatx4 *)p; }
     static __device__ inline void store4(float *p, floatx4 v) { *(floatx4 *)p = v; }
+    // 16 bytes of output channels per thread (EV = 4)
+    static constexpr int EV = 4;
+    static __device__ inline void loadv(const float *p, float (&v)[4]) {
+        floatx4 x = *(const floatx4 *)p;
+        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    }
+    static __device__ inline void storev(float *p, const float (&v)[4]) {
+        floatx4 x = {v[0], v[1], v[2], v[3]};
+        *(floatx4 *)p = x;
+    }
 };
 template <> struct Traits<_Float16> {
     static constexpr int VE = 8;
@@ -59,6 +69,19 @@ template <> struct Traits<_Float16> {
     static __device__ inline void store4(_Float16 *p, floatx4 v) {
         half4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         *(half4 *)p = h;
+    }
+    // 16 bytes of output channels per thread (EV = 8)
+    static constexpr int EV = 8;
+    static __device__ inline void loadv(const _Float16 *p, float (&v)[8]) {
+        half8 h = *(const half8 *)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    }
+    static __device__ inline void storev(_Float16 *p, const float (&v)[8]) {
+        half8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (_Float16)v[i];
+        *(half8 *)p = h;
     }
 };
 
@@ -372,20 +395,23 @@ void conv_igemm_kernel(const ConvBatch cb) {
     // ---- epilogue: the accumulator tiles -> LDS -> (sum over the K-group) -> fused
     //      bias/res/relu -> global, by all waves.  The residual rows are fetched first, so that
     //      their latency hides behind the accumulator hand-over through LDS. ----------------------
-    constexpr int LPR = BN / 4;                          // NHWC: threads per output row (4 channels each)
+    constexpr int EV = TR::EV;                           // NHWC: output channels per thread (16 bytes)
+    constexpr int LPR = BN / EV;                         // threads per output row
     constexpr int RPP = NT / LPR;                        // rows per pass
     constexpr int NPASS = (BM + RPP - 1) / RPP;
-    const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
-    floatx4 rv[NPASS];
+    const int c4 = (tid % LPR) * EV, r0 = tid / LPR;
+    float rv[NPASS][EV];
     if (OUT_MODE == OUT_NHWC) {
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) rv[ps] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int q = 0; q < EV; ++q) rv[ps][q] = 0.f;
         if (p.res_mode != RES_NONE && n0 + c4 < p.Nst) {
             const T *res = (const T *)p.res;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + r0, m = m0 + row;
-                if (row < BM && m < p.M) rv[ps] = TR::load4(res + (size_t)m * p.res_Cs + p.res_coff + n0 + c4);
+                if (row < BM && m < p.M) TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + n0 + c4, rv[ps]);
             }
         }
     }
@@ -409,7 +435,12 @@ void conv_igemm_kernel(const ConvBatch cb) {
     if (OUT_MODE == OUT_NHWC) {
         const int n = n0 + c4;
         if (n < p.Nst) {
-            const floatx4 bv = *(const floatx4 *)(bias + n);
+            float bv[EV];
+#pragma unroll
+            for (int q = 0; q < EV; q += 4) {
+                const floatx4 b4 = *(const floatx4 *)(bias + n + q);
+                bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
+            }
             T *out = (T *)p.out;
             const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
 #pragma unroll
@@ -418,17 +449,23 @@ void conv_igemm_kernel(const ConvBatch cb) {
                 const int m = m0 + row;
                 if (row < BM && m < p.M) {
                     const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
-                    floatx4 v = *(const floatx4 *)er;
+                    float v[EV];
 #pragma unroll
-                    for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(er + q * (64 * LDE));
-                    v += bv;
-                    if (p.res_mode == RES_PRE_RELU) v += rv[ps];
-                    if (p.relu) {
-                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    for (int q = 0; q < EV; q += 4) {
+                        floatx4 x = *(const floatx4 *)(er + q);
+#pragma unroll
+                        for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (64 * LDE) + q);
+                        v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
                     }
-                    if (p.res_mode == RES_POST_RELU) v += rv[ps];
-                    TR::store4(out + (size_t)m * p.Cos + cout_off + n, v);
+#pragma unroll
+                    for (int q = 0; q < EV; ++q) {
+                        float x = v[q] + bv[q];
+                        if (p.res_mode == RES_PRE_RELU) x += rv[ps][q];
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (p.res_mode == RES_POST_RELU) x += rv[ps][q];
+                        v[q] = x;
+                    }
+                    TR::storev(out + (size_t)m * p.Cos + cout_off + n, v);
                 }
             }
         }

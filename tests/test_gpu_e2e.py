@@ -116,6 +116,38 @@ def test_fp16_loose_gate(case):
         assert e["refine"] <= 1e-2 and e["refine_iou_min"] >= 0.995, e
 
 
+@pytest.mark.parametrize("variant", ["sharp", "base"])
+def test_fp16_tight_gate_vs_quant_oracle(variant):
+    """fp16 path against the quantisation-aware oracle (same rounding points: fp16 folded weights,
+    fp16 stored activations, wide accumulation): <= 2e-3 of max|ref| on every returned tensor and
+    every kept intermediate (SURVEY.md 8c tight gate); the loose gate above is against the fp32 truth."""
+    from oracle.np_oracle import QuantOracle
+    fixture = "synthetic_damped"
+    z = synth.smooth_image_batch(2, 127, stream0=11)
+    x = synth.smooth_image_batch(2, 255, stream0=11)
+    q = QuantOracle(synth.state_dict(variant, fixture), variant)
+    q.template(z)
+    qcls, qloc, qmask = q.track_mask(x)
+    m = _model(variant, fixture, "f16", True)
+    m.template(torch.from_numpy(z).cuda())
+    cls, loc, mask = m.track_mask(torch.from_numpy(x).cuda())
+    errs = {"zf": rel_err(m.debug_tensor("zf").cpu().numpy(), q.zf),
+            "search": rel_err(m.debug_tensor("search").cpu().numpy(), q.search),
+            "corr": rel_err(m.debug_tensor("corr").cpu().numpy(), _cat(q, "corr", ["cls", "loc", "mask"])),
+            "cls": rel_err(cls.cpu().numpy(), qcls), "loc": rel_err(loc.cpu().numpy(), qloc),
+            "mask": rel_err(mask.cpu().numpy(), qmask)}
+    for i, n in enumerate(("p0", "p1", "p2")):
+        errs[n] = rel_err(m.debug_tensor(n).cpu().numpy(), q.feature[i])
+    if variant == "sharp":
+        pos = np.array([[12, 12], [7, 16]], dtype=np.int32)
+        errs["refine"] = rel_err(m.track_refine(pos).cpu().numpy(), q.track_refine(pos))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "e2e_fp16_tight_%s.json" % variant), "w") as f:
+        json.dump(errs, f, indent=1)
+    bad = {k: v for k, v in errs.items() if not v <= 2e-3}
+    assert not bad, "fp16 tight gate %s: %s (all %s)" % (variant, bad, errs)
+
+
 def test_batch_invariance_and_order_errors():
     """B=2 equals two B=1 runs; call-order and batch-mismatch errors surface as exceptions."""
     g = load_golden("sharp_damped_b2")
