@@ -175,6 +175,9 @@ struct smk_ctx {
     bool prof = false;
     struct ProfRec { std::string id, kernel; double flop, bytes; hipEvent_t e0, e1; };
     std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_pool_next = 0;
+    bool mask_join_pending = false;
 };
 
 static const char *dtname(int dt) { return dt == DT_F16 ? "f16" : "f32"; }
@@ -185,7 +188,11 @@ struct ProfScope {
               double bytes) : c(c_), s(s_) {
         if (!c->prof) return;
         smk_ctx::ProfRec r{id, kernel, flop, bytes, nullptr, nullptr};
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        // events come from a pool created by smk_profile(1): creating them between launches
+        // stalled the stream at a fixed position (one layer read 10x too long)
+        if (c->prof_pool_next + 2 > c->prof_pool.size()) return;
+        r.e0 = c->prof_pool[c->prof_pool_next++];
+        r.e1 = c->prof_pool[c->prof_pool_next++];
         (void)hipEventRecord(r.e0, s);
         c->prof_recs.push_back(r);
         idx = (int)c->prof_recs.size() - 1;
@@ -674,8 +681,11 @@ static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
     return 0;
 }
 
+// defer_mask_join: the 63x63 mask head (HBM-write bound, nothing on the device reads it) is forked
+// to a side stream and only joined by the caller at the end of the frame step, so that it runs
+// beside the small decode / Refine launches instead of in front of them
 static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
-                     hipStream_t s) {
+                     hipStream_t s, bool defer_mask_join = false) {
     CHK(run_backbone(c, x, B, 255, s));
     const int nbt = nbranch(c);                                   // branches laid out in the buffers
     const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
@@ -709,7 +719,13 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     }
     if (want_mask) {
         ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
-        CHK(run_conv(c, "mask3", h0, nullptr, B, om, s));
+        if (defer_mask_join && !par && !c->prof && g_tune.mask_overlap && c->side[0]) {
+            CHK(stream_dep(c, s, c->side[0]));
+            CHK(run_conv(c, "mask3", h0, nullptr, B, om, c->side[0]));
+            c->mask_join_pending = true;
+        } else {
+            CHK(run_conv(c, "mask3", h0, nullptr, B, om, s));
+        }
     }
     if (par) { CHK(stream_dep(c, s_loc, s)); if (s_cls != s) CHK(stream_dep(c, s_cls, s)); }
     c->last_nb = nb;
@@ -881,6 +897,7 @@ int smk_destroy(smk_ctx *c) {
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
+    for (auto &e : c->prof_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->side[i]) hipStreamDestroy(c->side[i]);
     delete c;
     return 0;
@@ -983,6 +1000,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
@@ -992,8 +1010,13 @@ int smk_tune(const char *key, int value) {
 
 int smk_profile(smk_ctx *c, int enable) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
-    for (auto &r : c->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     c->prof_recs.clear();
+    c->prof_pool_next = 0;
+    if (enable && c->prof_pool.empty()) {
+        c->prof_pool.resize(2 * 1024);
+        for (auto &ev : c->prof_pool) HIPCHK(hipEventCreate(&ev));
+        HIPCHK(hipDeviceSynchronize());
+    }
     c->prof = enable != 0;
     return 0;
 }
@@ -1012,9 +1035,9 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
         if (it == idx.end()) { idx[r.id] = order.size(); order.push_back({r.id, Agg()}); it = idx.find(r.id); }
         Agg &a = order[it->second].second;
         a.kernel = r.kernel; a.ms += ms; a.flop += r.flop; a.bytes += r.bytes; a.calls++;
-        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     c->prof_recs.clear();
+    c->prof_pool_next = 0;
     std::string js = "[";
     for (size_t i = 0; i < order.size(); ++i) {
         char line[512];
@@ -1082,9 +1105,13 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const float *target_w
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     GraphKey key{3, B, flags, {x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) {
-        CHK(seq_track(c, x, B, flags, cls, loc, mask, st));
+        CHK(seq_track(c, x, B, flags, cls, loc, mask, st, true));
         CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
         if (refine_out) CHK(seq_refine(c, B, refine_out, st));
+        if (c->mask_join_pending) {
+            c->mask_join_pending = false;
+            CHK(stream_dep(c, c->side[0], st));
+        }
         return 0;
     });
     if (rc) return rc;
