@@ -83,6 +83,17 @@ int smk_set_weight(smk_ctx *ctx, const char *name, const float *data,
                    const int64_t *shape, int ndim);
 int smk_finalize_weights(smk_ctx *ctx);
 
+/* ---- packed-weight cache (replaces re-running utils/load_helper.py:30-54 +
+ * BN fold + repack on every start) ---------------------------------------------------------
+ * smk_export_packed serialises the BN-folded, MFMA-packed weights of a finalized ctx into one
+ * host blob (smk_packed_size bytes); smk_import_packed uploads such a blob instead of
+ * smk_set_weight* + smk_finalize_weights.  The blob records ABI version, dtype, variant and the
+ * packing constants; a mismatch is SMK_E_WEIGHT.  The CALLER keys the blob on the checkpoint
+ * (siammask_amd/custom.py hashes the state dict). */
+int smk_packed_size(smk_ctx *ctx, uint64_t *bytes);
+int smk_export_packed(smk_ctx *ctx, void *host_buf, uint64_t capacity);
+int smk_import_packed(smk_ctx *ctx, const void *host_buf, uint64_t bytes);
+
 /* ---- the four reference methods --------------------------------------------------------
  * smk_template  <- Custom.template(template)          custom.py:173-174
  *   z_dev: [B,3,127,127] f32 NCHW, raw 0..255 BGR (tools/test.py:61-64,152-155).

@@ -934,6 +934,111 @@ int smk_finalize_weights(smk_ctx *c) {
     return 0;
 }
 
+// ---- packed-weight cache: the BN-folded, MFMA-packed weights as one blob ----
+// layout: PackHeader | per conv: PackEntry, weight bytes [rows][Kpad] (dtype), bias [rows] f32
+struct PackHeader {
+    char magic[8];              // "SMKPACK1"
+    int32_t abi, dtype, variant, n_conv, npad_align, kpad_align;
+    uint64_t total_bytes;
+};
+struct PackEntry {
+    char id[24];
+    int32_t N, rows, group_rows, groups, Ci, k, K, Kpad;
+};
+
+static size_t packed_bytes(const smk_ctx *c) {
+    size_t n = sizeof(PackHeader);
+    for (auto &kv : c->conv)
+        n += sizeof(PackEntry) + (size_t)kv.second.rows * kv.second.Kpad * esize(c->dtype) + (size_t)kv.second.rows * 4;
+    return n;
+}
+
+int smk_packed_size(smk_ctx *c, uint64_t *bytes) {
+    if (!c || !bytes) return fail(SMK_E_ARG, "smk_packed_size: null argument");
+    if (!c->finalized) return fail(SMK_E_STATE, "smk_packed_size: weights not finalized");
+    *bytes = packed_bytes(c);
+    return 0;
+}
+
+int smk_export_packed(smk_ctx *c, void *host_buf, uint64_t capacity) {
+    if (!c || !host_buf) return fail(SMK_E_ARG, "smk_export_packed: null argument");
+    if (!c->finalized) return fail(SMK_E_STATE, "smk_export_packed: weights not finalized");
+    const size_t need = packed_bytes(c);
+    if (capacity < need) return fail(SMK_E_ARG, "smk_export_packed: buffer too small (%zu needed)", need);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    unsigned char *o = (unsigned char *)host_buf;
+    PackHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SMKPACK1", 8);
+    h.abi = smk_version(); h.dtype = c->dtype; h.variant = c->variant; h.n_conv = (int)c->conv.size();
+    h.npad_align = NPAD_ALIGN; h.kpad_align = KPAD_ALIGN; h.total_bytes = need;
+    memcpy(o, &h, sizeof(h)); o += sizeof(h);
+    for (auto &kv : c->conv) {
+        const PackedConv &pc = kv.second;
+        PackEntry en;
+        memset(&en, 0, sizeof(en));
+        if (kv.first.size() >= sizeof(en.id)) return fail(SMK_E_STATE, "internal: conv id too long");
+        memcpy(en.id, kv.first.c_str(), kv.first.size());
+        en.N = pc.N; en.rows = pc.rows; en.group_rows = pc.group_rows; en.groups = pc.groups;
+        en.Ci = pc.Ci; en.k = pc.k; en.K = pc.K; en.Kpad = pc.Kpad;
+        memcpy(o, &en, sizeof(en)); o += sizeof(en);
+        const size_t wb = (size_t)pc.rows * pc.Kpad * esize(c->dtype), bb = (size_t)pc.rows * 4;
+        HIPCHK(hipMemcpy(o, pc.w, wb, hipMemcpyDeviceToHost)); o += wb;
+        HIPCHK(hipMemcpy(o, pc.bias, bb, hipMemcpyDeviceToHost)); o += bb;
+    }
+    return 0;
+}
+
+int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
+    if (!c || !host_buf) return fail(SMK_E_ARG, "smk_import_packed: null argument");
+    if (bytes < sizeof(PackHeader)) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated blob");
+    const unsigned char *p = (const unsigned char *)host_buf, *end = p + bytes;
+    PackHeader h;
+    memcpy(&h, p, sizeof(h)); p += sizeof(h);
+    if (memcmp(h.magic, "SMKPACK1", 8) != 0) return fail(SMK_E_WEIGHT, "smk_import_packed: bad magic");
+    if (h.abi != smk_version() || h.dtype != c->dtype || h.variant != c->variant || h.npad_align != NPAD_ALIGN ||
+        h.kpad_align != KPAD_ALIGN)
+        return fail(SMK_E_WEIGHT, "smk_import_packed: blob was packed for abi %#x dtype %d variant %d (ctx: %#x %d %d)",
+                    h.abi, h.dtype, h.variant, smk_version(), c->dtype, c->variant);
+    if (h.total_bytes != bytes || h.n_conv < 1 || h.n_conv > 256) return fail(SMK_E_WEIGHT, "smk_import_packed: size mismatch");
+    HIPCHK(hipSetDevice(c->device));
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    c->conv.clear();
+    c->finalized = false;
+    for (int i = 0; i < h.n_conv; ++i) {
+        if (p + sizeof(PackEntry) > end) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated entry table");
+        PackEntry en;
+        memcpy(&en, p, sizeof(en)); p += sizeof(en);
+        en.id[sizeof(en.id) - 1] = 0;
+        if (en.rows < 1 || en.Kpad < 1 || en.rows % NPAD_ALIGN || en.Kpad % KPAD_ALIGN || en.K > en.Kpad)
+            return fail(SMK_E_WEIGHT, "smk_import_packed: entry %s has bad geometry", en.id);
+        const size_t wb = (size_t)en.rows * en.Kpad * esize(c->dtype), bb = (size_t)en.rows * 4;
+        if (p + wb + bb > end) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated data of %s", en.id);
+        PackedConv pc;
+        pc.N = en.N; pc.rows = en.rows; pc.group_rows = en.group_rows; pc.groups = en.groups;
+        pc.Ci = en.Ci; pc.k = en.k; pc.K = en.K; pc.Kpad = en.Kpad;
+        HIPCHK(hipMalloc(&pc.w, wb));
+        HIPCHK(hipMemcpy(pc.w, p, wb, hipMemcpyHostToDevice)); p += wb;
+        HIPCHK(hipMalloc((void **)&pc.bias, bb));
+        HIPCHK(hipMemcpy(pc.bias, p, bb, hipMemcpyHostToDevice)); p += bb;
+        c->conv[en.id] = pc;
+    }
+    // every convolution the variant launches must be present
+    static const char *need_all[] = {"stem", "adjust", "conv_kernel", "conv_search", "head0", "cls3", "loc3", "l1.0.ds", "l3.5.c3"};
+    for (const char *id : need_all)
+        if (!c->conv.count(id)) return fail(SMK_E_WEIGHT, "smk_import_packed: blob lacks %s", id);
+    if (c->variant != SMK_VARIANT_RPN && !c->conv.count("mask3")) return fail(SMK_E_WEIGHT, "smk_import_packed: blob lacks mask3");
+    if (c->variant == SMK_VARIANT_SHARP && (!c->conv.count("deconv") || !c->conv.count("post2")))
+        return fail(SMK_E_WEIGHT, "smk_import_packed: blob lacks the Refine convolutions");
+    c->finalized = true;
+    c->template_B = 0;
+    c->track_B = 0;
+    return 0;
+}
+
 int smk_set_graph_mode(smk_ctx *c, int enable) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
     c->graph_mode = enable != 0;

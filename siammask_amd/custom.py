@@ -63,11 +63,15 @@ class Custom(nn.Module):
     graph      replay captured hipGraphs (default: env SIAMMASK_AMD_GRAPH, else on).
     lazy_mask  sharp only: skip the 3969-channel mask head in track_mask (its result is never
                read when track_refine is used, tools/test.py:256-258) and return None for it.
+    pack_cache directory of the packed-weight cache, or None (default: env
+               SIAMMASK_AMD_PACK_CACHE, else off).  The BN-folded, MFMA-packed weights are stored as
+               <sha256(state dict, dtype, variant, ABI)>.smkpack and uploaded from there on later
+               starts instead of folding and repacking the checkpoint again.
     """
     variant = None
 
     def __init__(self, pretrain=False, anchors=None, o_sz=127, g_sz=127, dtype=None, max_batch=1,
-                 graph=None, lazy_mask=False, **kwargs):
+                 graph=None, lazy_mask=False, pack_cache=None, **kwargs):
         super(Custom, self).__init__()
         if anchors is None:
             raise ValueError("Custom(anchors=...) is required (tools/test.py:560)")
@@ -91,6 +95,8 @@ class Custom(nn.Module):
             graph = os.environ.get("SIAMMASK_AMD_GRAPH", "1") != "0"
         self._graph = bool(graph)
         self._lazy_mask = bool(lazy_mask)
+        self._pack_cache = pack_cache if pack_cache is not None else os.environ.get("SIAMMASK_AMD_PACK_CACHE") or None
+        self.pack_cache_hit = None          # True / False after the weights were (re)loaded with a cache dir
         self._max_batch = int(max_batch)
         self._ctx = None
         self._ctx_device = None
@@ -121,6 +127,76 @@ class Custom(nn.Module):
                                % (x.device if isinstance(x, torch.Tensor) else type(x)))
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         L = _lib.lib()
+        self._ensure_ctx(dev, batch)
+        if self._weights_dirty:
+            sd = [(name, np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy()))
+                  for name, t in self.state_dict().items() if not name.endswith("num_batches_tracked")]
+            path = self._pack_path(sd) if self._pack_cache else None
+            loaded = False
+            if path and os.path.exists(path):
+                try:
+                    self._import_packed(path)
+                    loaded = True
+                except _lib.SmkError:
+                    loaded = False          # stale or foreign blob: fall through and rebuild it
+            if not loaded:
+                for name, a in sd:
+                    shape = (ctypes.c_int64 * max(1, a.ndim))(*a.shape)
+                    _lib.check(L.smk_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                                shape, a.ndim))
+                _lib.check(L.smk_finalize_weights(self._ctx))
+                if path:
+                    self.save_packed(path)
+            if path:
+                self.pack_cache_hit = loaded
+            self._weights_dirty = False
+            self._tracked = 0
+            self.zf = None
+
+    # -- packed-weight cache --------------------------------------------------
+    def _pack_path(self, sd):
+        import hashlib
+        h = hashlib.sha256()
+        h.update(("%s|%s|abi%#x" % (self.variant, self._dtype, _lib.lib().smk_version())).encode())
+        for name, a in sd:
+            h.update(name.encode())
+            h.update(str(a.shape).encode())
+            h.update(a.tobytes())
+        return os.path.join(self._pack_cache, "siammask_%s_%s_%s.smkpack" % (self.variant, self._dtype, h.hexdigest()[:32]))
+
+    def save_packed(self, path):
+        """Write the BN-folded, MFMA-packed weights of this (finalized) model to ``path``."""
+        if self._ctx is None:
+            raise RuntimeError("save_packed(): no device context yet (run template() first)")
+        L = _lib.lib()
+        n = ctypes.c_uint64(0)
+        _lib.check(L.smk_packed_size(self._ctx, ctypes.byref(n)))
+        buf = (ctypes.c_ubyte * n.value)()
+        _lib.check(L.smk_export_packed(self._ctx, buf, n.value))
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = "%s.tmp%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(bytes(buf))
+        os.replace(tmp, path)                # atomic: concurrent ranks may race on the same file
+
+    def _import_packed(self, path):
+        with open(path, "rb") as f:
+            blob = f.read()
+        buf = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
+        _lib.check(_lib.lib().smk_import_packed(self._ctx, buf, len(blob)))
+
+    def load_packed(self, path, device=None):
+        """Upload packed weights written by save_packed(); the module's parameters are NOT updated
+        (they are only the checkpoint container) -- use for serving starts without a checkpoint."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ensure_ctx(dev.index if dev.index is not None else torch.cuda.current_device(), self._max_batch)
+        self._import_packed(path)
+        self._weights_dirty = False
+        self._tracked = 0
+        self.zf = None
+
+    def _ensure_ctx(self, dev, batch):
+        L = _lib.lib()
         if self._ctx is not None and (dev != self._ctx_device or batch > self._max_batch):
             self._destroy()
         if self._ctx is None:
@@ -134,18 +210,6 @@ class Custom(nn.Module):
             self._hp_dirty = True
             self._io = {}
             self._fast = {}
-        if self._weights_dirty:
-            for name, t in self.state_dict().items():
-                if name.endswith("num_batches_tracked"):
-                    continue
-                a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
-                shape = (ctypes.c_int64 * max(1, a.ndim))(*a.shape)
-                _lib.check(L.smk_set_weight(self._ctx, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
-                                            shape, a.ndim))
-            _lib.check(L.smk_finalize_weights(self._ctx))
-            self._weights_dirty = False
-            self._tracked = 0
-            self.zf = None
 
     def _destroy(self):
         if self._ctx is not None:

@@ -227,3 +227,57 @@ def test_fused_step_equals_separate_calls(dtype):
     assert torch.equal(out["refine"], ref)
     if dtype == "f32":
         assert rel_err(out["refine"].cpu().numpy(), g["refine"]) <= 1e-4
+
+
+def test_packed_weight_cache(tmp_path):
+    """packed-weight cache keyed on the checkpoint.  A hit uploads the stored blob and
+    gives bit-identical outputs; a changed checkpoint or a damaged blob is a miss (rebuilt); a blob of
+    another dtype is rejected by the library."""
+    from siammask_amd import _lib
+    from siammask_amd.custom import build
+    cache = str(tmp_path / "packs")
+    sd = synth.torch_state_dict("sharp", "synthetic_damped")
+    z = torch.from_numpy(synth.smooth_image_batch(1, 127, stream0=3)).cuda()
+    x = torch.from_numpy(synth.smooth_image_batch(1, 255, stream0=3)).cuda()
+
+    def run(m):
+        m.template(z)
+        cls, loc, mask = m.track_mask(x)
+        ref = m.track_refine((12, 11))
+        return [t.clone() for t in (cls, loc, mask, ref)]
+
+    def make(dtype="f16", state=sd):
+        m = build("sharp", dtype=dtype, pack_cache=cache)
+        m.load_state_dict(state)
+        return m.eval().cuda()
+
+    m1 = make()
+    o1 = run(m1)
+    assert m1.pack_cache_hit is False
+    files = os.listdir(cache)
+    assert len(files) == 1 and files[0].endswith(".smkpack")
+    m2 = make()
+    o2 = run(m2)
+    assert m2.pack_cache_hit is True
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    # a different checkpoint is a different key
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["rpn_model.cls.head.3.bias"] += 0.5
+    m3 = make(state=sd2)
+    o3 = run(m3)
+    assert m3.pack_cache_hit is False and len(os.listdir(cache)) == 2
+    assert not torch.equal(o3[0], o1[0])
+    # a damaged blob is rebuilt, not trusted
+    path = os.path.join(cache, files[0])
+    blob = bytearray(open(path, "rb").read())
+    open(path, "wb").write(bytes(blob[:len(blob) // 2]))
+    m4 = make()
+    o4 = run(m4)
+    assert m4.pack_cache_hit is False
+    for a, b in zip(o1, o4):
+        assert torch.equal(a, b)
+    # explicit load of a blob packed for another dtype fails loudly
+    m5 = build("sharp", dtype="f32")
+    with pytest.raises(_lib.SmkError):
+        m5.load_packed(path, device="cuda:0")

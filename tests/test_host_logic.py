@@ -149,3 +149,19 @@ def test_upsample_map_equals_torch():
         t = torch.arange(hin, dtype=torch.float32).view(1, 1, hin, 1).expand(1, 1, hin, hin).contiguous()
         up = F.interpolate(t, size=(hout, hout), mode="nearest")[0, 0, :, 0].numpy().astype(int)
         assert (up == (np.arange(hout) * hin) // hout).all()
+
+
+def test_pack_cache_key_follows_the_checkpoint(tmp_path):
+    """the packed-weight cache is keyed on (state dict, dtype, variant, ABI)."""
+    import numpy as np
+    from siammask_amd.custom import build
+    a = build("rpn", dtype="f16", pack_cache=str(tmp_path))
+    sd = [("w", np.arange(6, dtype=np.float32).reshape(2, 3)), ("b", np.zeros(2, dtype=np.float32))]
+    p0 = a._pack_path(sd)
+    assert p0 == a._pack_path([(n, v.copy()) for n, v in sd])
+    sd2 = [("w", sd[0][1] + 1e-3), sd[1]]
+    assert a._pack_path(sd2) != p0
+    b = build("rpn", dtype="f32", pack_cache=str(tmp_path))
+    assert b._pack_path(sd) != p0
+    c = build("base", dtype="f16", pack_cache=str(tmp_path))
+    assert c._pack_path(sd) != p0
