@@ -198,6 +198,24 @@ int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, in
 int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W,
                         float *y_dev, void *stream);
 
+/* ---- image ops either side of the network (additive) -----------------
+ * smk_crop_resize <- tools/test.py:67-110 get_subwindow_tracking for B streams.
+ *   frames_dev: uint8 [H][W][3] (as cv2.imread gives it); frame_stride_bytes = 0 when all streams
+ *   crop the same frame (multi-object), else the byte distance between per-stream frames.
+ *   boxes (host): B x (xmin, ymin, sz) = the integer window of tools/test.py:74-86 in un-padded
+ *   frame coordinates (it may stick out of the frame); avg_bgr (host): B x 3 uint8 mean colour.
+ *   out_dev: f32 [B,3,model_sz,model_sz].  Resize = cv2.resize INTER_LINEAR on uint8.
+ * smk_paste_mask  <- tools/test.py:257-284: sigmoid(logits [B,ms*ms]) -> crop_back (cv2.warpAffine,
+ *   INTER_LINEAR, BORDER_CONSTANT `border`) into a W x H frame -> (prob > seg_thr) as uint8.
+ *   inv_map (host): B x 6 doubles, the INVERSE (dst -> src) affine map cv2.warpAffine derives from
+ *   crop_back's mapping.  mask_out_dev [B,H,W] uint8 and/or prob_out_dev [B,H,W] f32. */
+int smk_crop_resize(const uint8_t *frames_dev, int64_t frame_stride_bytes, int H, int W,
+                    const int32_t *boxes, const uint8_t *avg_bgr, int B, int model_sz,
+                    float *out_dev, void *stream);
+int smk_paste_mask(const float *logits_dev, int mask_size, const double *inv_map, int B, int W,
+                   int H, float seg_thr, float border, uint8_t *mask_out_dev, float *prob_out_dev,
+                   void *stream);
+
 /* measurement aid: time `iters` back-to-back launches of the MFMA conv kernel for geometry g
  * (random f16/f32 operands allocated internally, NHWC epilogue unless algo low byte is 2) with
  * HIP events on `stream`; *usec_out = average microseconds per launch.  algo as above. */

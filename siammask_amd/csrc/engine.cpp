@@ -1409,6 +1409,49 @@ int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int 
     return 0;
 }
 
+// ---- image ops either side of the network ------------------------------
+int smk_crop_resize(const uint8_t *frames_dev, int64_t frame_stride_bytes, int H, int W, const int32_t *boxes,
+                    const uint8_t *avg_bgr, int B, int model_sz, float *out_dev, void *stream) {
+    if (!frames_dev || !boxes || !avg_bgr || !out_dev) return fail(SMK_E_ARG, "smk_crop_resize: null argument");
+    if (H < 1 || W < 1 || model_sz < 1 || B < 1) return fail(SMK_E_ARG, "smk_crop_resize: bad geometry");
+    for (int b0 = 0; b0 < B; b0 += CROP_MAX_B) {
+        const int nb = B - b0 < CROP_MAX_B ? B - b0 : CROP_MAX_B;
+        CropParams p;
+        memset(&p, 0, sizeof(p));
+        p.frames = frames_dev + (size_t)b0 * frame_stride_bytes;
+        p.frame_stride = frame_stride_bytes;
+        p.out = out_dev + (size_t)b0 * 3 * model_sz * model_sz;
+        p.H = H; p.W = W; p.model_sz = model_sz;
+        for (int i = 0; i < nb; ++i) {
+            const int32_t *bx = boxes + 3 * (b0 + i);
+            if (bx[2] < 1 || bx[2] > 32768) return fail(SMK_E_ARG, "smk_crop_resize: window size %d out of range", bx[2]);
+            p.box[i][0] = bx[0]; p.box[i][1] = bx[1]; p.box[i][2] = bx[2];
+            for (int k = 0; k < 3; ++k) p.avg[i][k] = avg_bgr[3 * (b0 + i) + k];
+        }
+        if (launch_crop_resize(p, nb, stream)) return fail(SMK_E_HIP, "crop_resize launch failed");
+    }
+    return 0;
+}
+
+int smk_paste_mask(const float *logits_dev, int mask_size, const double *inv_map, int B, int W, int H, float seg_thr,
+                   float border, uint8_t *mask_out_dev, float *prob_out_dev, void *stream) {
+    if (!logits_dev || !inv_map || (!mask_out_dev && !prob_out_dev)) return fail(SMK_E_ARG, "smk_paste_mask: null argument");
+    if (W < 1 || H < 1 || mask_size < 1 || B < 1) return fail(SMK_E_ARG, "smk_paste_mask: bad geometry");
+    for (int b0 = 0; b0 < B; b0 += CROP_MAX_B) {
+        const int nb = B - b0 < CROP_MAX_B ? B - b0 : CROP_MAX_B;
+        PasteParams p;
+        memset(&p, 0, sizeof(p));
+        p.logits = logits_dev + (size_t)b0 * mask_size * mask_size;
+        p.mask_out = mask_out_dev ? mask_out_dev + (size_t)b0 * H * W : nullptr;
+        p.prob_out = prob_out_dev ? prob_out_dev + (size_t)b0 * H * W : nullptr;
+        p.ms = mask_size; p.W = W; p.H = H; p.seg_thr = seg_thr; p.border = border;
+        for (int i = 0; i < nb; ++i)
+            for (int k = 0; k < 6; ++k) p.inv_map[i][k] = inv_map[6 * (b0 + i) + k];
+        if (launch_paste_mask(p, nb, stream)) return fail(SMK_E_HIP, "paste_mask launch failed");
+    }
+    return 0;
+}
+
 // time repeated launches of one conv geometry (operands are pseudo-random, not zeros: DVFS hygiene)
 int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, int iters, float *usec_out,
                    void *stream) {

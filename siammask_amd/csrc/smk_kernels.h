@@ -155,6 +155,25 @@ struct DecodeParams {
     double penalty_k, window_influence;
 };
 
+// image ops either side of the network (image_kernels.hip); per-stream scalars travel in the kernarg
+constexpr int CROP_MAX_B = 32;
+struct CropParams {
+    const unsigned char *frames;   // [B or 1][H][W][3] uint8 (BGR as cv2.imread gives it)
+    long frame_stride;             // bytes between per-stream frames (0: all streams share one frame)
+    float *out;                    // [B][3][model_sz][model_sz] f32
+    int H, W, model_sz;
+    int box[CROP_MAX_B][3];        // xmin, ymin, sz  (un-padded frame coordinates)
+    unsigned char avg[CROP_MAX_B][4];
+};
+struct PasteParams {
+    const float *logits;           // [B][ms*ms] refine mask logits
+    unsigned char *mask_out;       // [B][H][W] (prob > seg_thr) or nullptr
+    float *prob_out;               // [B][H][W] warped probability or nullptr
+    int ms, W, H;
+    float seg_thr, border;
+    double inv_map[CROP_MAX_B][6]; // inverse affine map (dst -> src), row major 2x3
+};
+
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 struct TileChoice { int bm, bn, kt, stages; };
 TileChoice choose_tile(const ConvParams &p, int dtype);
@@ -166,6 +185,8 @@ int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
+int launch_crop_resize(const CropParams &p, int B, void *stream);
+int launch_paste_mask(const PasteParams &p, int B, void *stream);
 const void *zero_page();   // device-resident 8 KB of zeros (allocated on first use, per device)
 
 }  // namespace smk
