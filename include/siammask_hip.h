@@ -215,6 +215,10 @@ int smk_crop_resize(const uint8_t *frames_dev, int64_t frame_stride_bytes, int H
 int smk_paste_mask(const float *logits_dev, int mask_size, const double *inv_map, int B, int W,
                    int H, float seg_thr, float border, uint8_t *mask_out_dev, float *prob_out_dev,
                    void *stream);
+/* multi-object fusion of tools/test.py:521-523 in the same pass: labels [H,W] uint8 =
+ * (argmax_o prob_o + 1) * (max_o prob_o > seg_thr) over n_obj objects that share the frame */
+int smk_paste_labels(const float *logits_dev, int mask_size, const double *inv_map, int n_obj, int W,
+                     int H, float seg_thr, float border, uint8_t *labels_out_dev, void *stream);
 
 /* measurement aid: time `iters` back-to-back launches of the MFMA conv kernel for geometry g
  * (random f16/f32 operands allocated internally, NHWC epilogue unless algo low byte is 2) with

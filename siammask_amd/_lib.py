@@ -27,7 +27,7 @@ SYMBOLS = (
     "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode",
     "smk_debug_read", "smk_tune", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
-    "smk_import_packed", "smk_crop_resize", "smk_paste_mask",
+    "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
 )
 
 
@@ -97,6 +97,7 @@ def lib():
     L.smk_import_packed.argtypes = [vp, vp, ctypes.c_uint64]
     L.smk_crop_resize.argtypes = [vp, ctypes.c_int64, ci, ci, vp, vp, ci, ci, fp, vp]
     L.smk_paste_mask.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, fp, vp]
+    L.smk_paste_labels.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, vp]
     L.smk_bench_conv.argtypes = [ci, ci, gp, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
     for name in SYMBOLS:
         fn = getattr(L, name)

@@ -1452,6 +1452,21 @@ int smk_paste_mask(const float *logits_dev, int mask_size, const double *inv_map
     return 0;
 }
 
+int smk_paste_labels(const float *logits_dev, int mask_size, const double *inv_map, int n_obj, int W, int H,
+                     float seg_thr, float border, uint8_t *labels_out_dev, void *stream) {
+    if (!logits_dev || !inv_map || !labels_out_dev) return fail(SMK_E_ARG, "smk_paste_labels: null argument");
+    if (W < 1 || H < 1 || mask_size < 1 || n_obj < 1 || n_obj > CROP_MAX_B)
+        return fail(SMK_E_ARG, "smk_paste_labels: bad geometry (1..%d objects)", CROP_MAX_B);
+    PasteParams p;
+    memset(&p, 0, sizeof(p));
+    p.logits = logits_dev; p.mask_out = labels_out_dev;
+    p.ms = mask_size; p.W = W; p.H = H; p.seg_thr = seg_thr; p.border = border;
+    for (int i = 0; i < n_obj; ++i)
+        for (int k = 0; k < 6; ++k) p.inv_map[i][k] = inv_map[6 * i + k];
+    if (launch_paste_labels(p, n_obj, stream)) return fail(SMK_E_HIP, "paste_labels launch failed");
+    return 0;
+}
+
 // time repeated launches of one conv geometry (operands are pseudo-random, not zeros: DVFS hygiene)
 int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, int iters, float *usec_out,
                    void *stream) {

@@ -86,14 +86,12 @@ int launch_crop_resize(const CropParams &p, int B, void *stream) {
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void paste_mask_kernel(const PasteParams p) {
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= p.W) return;
+// warped probability of stream b at frame pixel (x, y): WarpAffineInvoker + remapBilinear<float>
+__device__ __forceinline__ float warped_prob(const PasteParams &p, int b, int x, int y) {
     const double *M = p.inv_map[b];
     constexpr int AB_BITS = 10, INTER_BITS = 5, TAB = 1 << INTER_BITS;
     constexpr double AB_SCALE = 1024.0;
-    // WarpAffineInvoker: X = (X0(y) + adelta(x)) >> (AB_BITS - INTER_BITS), round_delta = 16
+    // X = (X0(y) + adelta(x)) >> (AB_BITS - INTER_BITS), round_delta = AB_SCALE / TAB / 2 = 16
     const long adelta = (long)__builtin_rint(__dmul_rn(__dmul_rn(M[0], (double)x), AB_SCALE));
     const long bdelta = (long)__builtin_rint(__dmul_rn(__dmul_rn(M[3], (double)x), AB_SCALE));
     const long X0 = (long)__builtin_rint(__dmul_rn(__dadd_rn(__dmul_rn(M[1], (double)y), M[2]), AB_SCALE)) + 16;
@@ -119,15 +117,44 @@ __global__ __launch_bounds__(256) void paste_mask_kernel(const PasteParams p) {
     v = __fadd_rn(v, __fmul_rn(tap(sy, sx + 1), w01));
     v = __fadd_rn(v, __fmul_rn(tap(sy + 1, sx), w10));
     v = __fadd_rn(v, __fmul_rn(tap(sy + 1, sx + 1), w11));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void paste_mask_kernel(const PasteParams p) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= p.W) return;
+    const float v = warped_prob(p, b, x, y);
     const size_t o = ((size_t)b * p.H + y) * p.W + x;
     if (p.prob_out) p.prob_out[o] = v;
     if (p.mask_out) p.mask_out[o] = v > p.seg_thr ? 1 : 0;
+}
+
+// multi-object fusion (tools/test.py:521-523): label = (argmax_o prob_o + 1) * (max_o prob_o > thr);
+// np.argmax keeps the first maximum
+__global__ __launch_bounds__(256) void paste_labels_kernel(const PasteParams p, int n_obj) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= p.W) return;
+    float best = warped_prob(p, 0, x, y);
+    int arg = 0;
+    for (int o = 1; o < n_obj; ++o) {
+        const float v = warped_prob(p, o, x, y);
+        if (v > best) { best = v; arg = o; }
+    }
+    p.mask_out[(size_t)y * p.W + x] = best > p.seg_thr ? (unsigned char)(arg + 1) : 0;
 }
 
 int launch_paste_mask(const PasteParams &p, int B, void *stream) {
     if (B < 1 || B > CROP_MAX_B) return -1;
     dim3 grid((p.W + 255) / 256, p.H, B);
     hipLaunchKernelGGL(paste_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_paste_labels(const PasteParams &p, int n_obj, void *stream) {
+    if (n_obj < 1 || n_obj > CROP_MAX_B || !p.mask_out) return -1;
+    dim3 grid((p.W + 255) / 256, p.H, 1);
+    hipLaunchKernelGGL(paste_labels_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, n_obj);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

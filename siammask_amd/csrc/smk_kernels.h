@@ -187,6 +187,7 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);
+int launch_paste_labels(const PasteParams &p, int n_obj, void *stream);
 const void *zero_page();   // device-resident 8 KB of zeros (allocated on first use, per device)
 
 }  // namespace smk

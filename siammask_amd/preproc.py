@@ -97,3 +97,22 @@ def paste_masks(logits, back_boxes, im_wh, seg_thr=0.35, padding=-1.0, want_prob
             logits.data_ptr(), ms, inv.ctypes.data_as(ctypes.c_void_p), B, W, H, float(seg_thr), float(padding),
             mask.data_ptr(), prob.data_ptr() if prob is not None else None, _lib.current_stream_ptr()))
     return (mask, prob) if want_prob else mask
+
+
+def paste_labels(logits, back_boxes, im_wh, seg_thr=0.35, padding=-1.0):
+    """Multi-object VOS fusion (tools/test.py:521-523) fused with the paste-back: the O objects of one
+    frame -> uint8 label map [im_h, im_w] = (argmax_o prob_o + 1) * (max_o prob_o > seg_thr)."""
+    _need_cuda(logits, "logits")
+    logits = logits.contiguous().float()
+    O = logits.shape[0]
+    ms = int(round(logits[0].numel() ** 0.5))
+    if ms * ms != logits[0].numel() or len(back_boxes) != O:
+        raise ValueError("logits must be [O, ms*ms] with one back_box per object")
+    W, H = int(im_wh[0]), int(im_wh[1])
+    inv = np.ascontiguousarray(np.stack([invert_affine(crop_back_map(bb, (W, H))) for bb in back_boxes]))
+    labels = torch.empty((H, W), dtype=torch.uint8, device=logits.device)
+    with torch.cuda.device(logits.device):
+        _lib.check(_lib.lib().smk_paste_labels(logits.data_ptr(), ms, inv.ctypes.data_as(ctypes.c_void_p), O, W, H,
+                                               float(seg_thr), float(padding), labels.data_ptr(),
+                                               _lib.current_stream_ptr()))
+    return labels

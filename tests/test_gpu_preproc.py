@@ -89,6 +89,26 @@ def test_paste_mask_matches_warp_affine_restatement():
         assert 0 < wm.sum() < wm.size
 
 
+def test_paste_labels_multi_object_fusion():
+    """tools/test.py:521-523 fused into the paste-back kernel"""
+    from siammask_amd import preproc
+    rng = np.random.default_rng(11)
+    O, W, H = 3, 200, 150
+    yy, xx = np.mgrid[0:127, 0:127]
+    logits = np.stack([5.0 * np.cos((xx - 40 * o) / 15.0) * np.cos((yy - 30 * o) / 13.0) + rng.normal(0, 0.3, (127, 127))
+                       for o in range(O)]).astype(np.float32)
+    bbs = [C.back_box([20.0 + 30 * o, 10.0 + 20 * o, 150.0, 150.0], (12, 12), (W, H)) for o in range(O)]
+    lab = preproc.paste_labels(torch.from_numpy(logits.reshape(O, -1)).cuda(), bbs, (W, H), 0.35).cpu().numpy()
+    probs = np.stack([C.paste_mask(logits[o], bbs[o], (W, H), 0.35)[1] for o in range(O)])
+    want = ((np.argmax(probs, axis=0).astype("uint8") + 1) * (np.max(probs, axis=0) > 0.35).astype("uint8"))
+    diff = lab != want
+    # only pixels where two objects tie or the maximum sits on the threshold (within the exp ulp) may differ
+    srt = np.sort(probs, axis=0)
+    near = (np.abs(srt[-1] - 0.35) <= 5e-7) | (np.abs(srt[-1] - srt[-2]) <= 5e-7)
+    assert np.all(near[diff]) and diff.mean() < 1e-3
+    assert set(np.unique(want)) >= {0, 1, 2, 3}
+
+
 def test_preproc_rejects_cpu_tensors():
     from siammask_amd import preproc
     with pytest.raises(RuntimeError):
