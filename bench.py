@@ -193,6 +193,17 @@ def roofline(w, steps=3):
                             "tflops": round(heavy["flop"] / (heavy["ms"] * 1e-3) / 1e12, 2)},
         "kernel_ms_per_step": round(total_ms / steps, 4),
     }
+    # HBM bytes per launch from the PMC counters (collected offline by tests/gpu_pmc.sh with rocprofv3
+    # --pmc in separate passes and committed under profiles/; cannot be sampled from inside this process)
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % w.name)
+    if os.path.exists(pmc):
+        try:
+            t = json.load(open(pmc))
+            out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
+            out["traffic_note"] = "bytes per conv_igemm launch; %s; %s" % (t["source"], t["correction"])
+        except Exception:  # noqa: BLE001
+            pass
+    out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))
     if xc and xc["ms"] > 0:
         out["dw_xcorr"] = {"bound": "hbm", "achieved_GBps": round(xc["bytes"] / (xc["ms"] * 1e-3) / 1e9, 1),
                            "peak_GBps": 8000.0, "us": round(xc["ms"] * 1e3 / xc["calls"], 2)}
