@@ -138,9 +138,13 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const float
  * I/O pointers), so keep the I/O buffers stable to hit the cache. */
 int smk_set_graph_mode(smk_ctx *ctx, int enable);
 
-/* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured
- * work): "xcd_mode" 0|1|2, "force_tile" 0..5, "min_blocks_x16", "stages" 0|2|3|4, "kt" 0|128|256 (K-tile bytes), "concurrency" 0|1
- * (the latter applies to contexts created afterwards). */
+/* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured work):
+ *   "force_tile" 0 auto | 1 128x128 | 2 128x64 | 3 64x128 | 4 64x64 | 5 256x128   "kt" 0|128|256 (K-tile bytes)
+ *   "stages" 0|2|3|4 (LDS ring depth)     "xcd_mode" 0|1|2 (tile -> XCD order)   "min_blocks_x16" (tile thresholds)
+ *   "merge" 0|1 (independent convolutions share a launch)   "nt_store" 0|1 (streaming stores of the mask logits)
+ *   "prio" -1..3 (s_setprio of the consumer waves; measured null)   "mask_overlap" 0|1 (mask head on a graph side
+ *   branch; measured slower)   "concurrency" 0|1 (fork/join between independent launches; measured slower; applies to
+ *   contexts created afterwards). */
 int smk_tune(const char *key, int value);
 
 /* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the

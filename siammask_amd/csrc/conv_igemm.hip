@@ -10,16 +10,13 @@
 // bias (+ residual) (+ ReLU) and writes NHWC in the activation dtype, or NCHW fp32 for the
 // tensors handed back to the caller.
 //
-// Tiling (wave64, 4 waves = 2x2 per workgroup):
-//   workgroup tile BM x BN in {64,128}^2, K tile = 128 bytes per row (64 f16 / 32 f32),
-//   each wave owns (BM/2)x(BN/2) as 32x32 MFMA fragments:
-//     f16: v_mfma_f32_32x32x16_f16   (one per 32 bytes of K)
-//     f32: v_mfma_f32_32x32x2_f32    (four per 32 bytes of K; exact fp32 fma chain)
-//   A and B tiles are staged global -> VGPR -> LDS (the gather needs per-lane predication),
-//   double buffered, one barrier per K tile, loads of tile t+1 in flight under the MFMAs of
-//   tile t.  LDS rows are 128 B with the 16-byte slot XOR-swizzled by (row>>1)&7 so that the
-//   ds_read_b128 fragment reads are bank-conflict free.  The accumulators go back through
-//   LDS once so that global stores (and residual loads) are row-contiguous.
+// Structure (details at the kernel): workgroup = 4 or 8 CONSUMER waves (each owns a 64x64
+// accumulator tile of 2x2 MFMA 32x32 fragments; f16: v_mfma_f32_32x32x16_f16, f32:
+// v_mfma_f32_32x32x2_f32, an exact fp32 fma chain) + 4 PRODUCER waves that gather the A rows and the
+// weight rows straight into an LDS ring with LDS-DMA (global_load_lds_dwordx4, 16 bytes per lane,
+// XOR-swizzled on the source side so that the ds_read_b128 fragment reads are bank-conflict free).
+// One s_barrier per K tile hands a tile from the producers to the consumers.  The accumulators go
+// back through LDS once so that global stores (and residual loads) are 16-byte row-contiguous.
 #include <hip/hip_runtime.h>
 #include "smk_kernels.h"
 
