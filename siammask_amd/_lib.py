@@ -104,6 +104,10 @@ def lib():
         if name not in ("smk_last_error",):
             fn.restype = ci
     _lib = L
+    # SMK_TUNE="key=value,key=value": library tuning knobs from the environment (A/B runs of the test-suite)
+    for kv in filter(None, os.environ.get("SMK_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        check(L.smk_tune(k.strip().encode(), int(v)))
     return L
 
 

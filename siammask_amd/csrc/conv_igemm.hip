@@ -228,6 +228,14 @@ void conv_igemm_kernel(const ConvBatch cb) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             wsrc[i] = (const char *)(wgt + (size_t)(n0 + lrow + RPR * i) * p.Kpad + slot * VE);
+        // buffer-resource form of the same loads (p.buf_lds): 32-bit offsets against an SRD whose
+        // hardware range check returns zeros for every out-of-range lane, so padding needs no
+        // zero page and no memory traffic at all
+        const bool use_buf = p.buf_lds != 0;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, p.w_bytes, 0x00020000);
+        const long w_base = (const char *)wgt - (const char *)p.wgt;
+        constexpr long OOB = 0x7ffff000;                   // >= num_records (tensors are < 2 GB in this mode)
 
         // This thread always fetches the same 16-byte slot of every K tile, i.e. K index
         // kt*BK + slot*VE.  Its (tap, channel) position is decoded per tile with a shift (Ci is a
@@ -258,7 +266,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
                 }
                 ok = ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
                 const long off = (((long)(ri[i].b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off) * (long)sizeof(T);
-                a_off[i] = ok ? off : zero_off;
+                a_off[i] = ok ? off : (use_buf ? OOB : zero_off);
             }
         };
         auto set_tile = [&](int kt) {
@@ -282,10 +290,21 @@ void conv_igemm_kernel(const ConvBatch cb) {
         auto issue_tile = [&](int kt, int buf) {
             unsigned char *sA = smem + buf * STAGE_BYTES + pw * 1024;
             const long cb = (long)cur_c * (long)sizeof(T), kb = (long)kt * KT;
+            if (use_buf) {
 #pragma unroll
-            for (int j = 0; j < RA; ++j) glds16(in + a_off[j] + cb, sA + j * 4096);
+                for (int j = 0; j < RA; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(sA + j * 4096), 16,
+                                                             (int)(a_off[j] + cb), 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < RB; ++j) glds16(wsrc[j] + kb, sA + BM * KT + j * 4096);
+                for (int j = 0; j < RB; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(sA + BM * KT + j * 4096), 16,
+                                                             (int)(wsrc[j] - (const char *)wgt + w_base), (int)kb, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < RA; ++j) glds16(in + a_off[j] + cb, sA + j * 4096);
+#pragma unroll
+                for (int j = 0; j < RB; ++j) glds16(wsrc[j] + kb, sA + BM * KT + j * 4096);
+            }
         };
 
 #pragma unroll

@@ -496,6 +496,12 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     }
     p.xcd_mode = g_tune.xcd_mode;
     p.prio = g_tune.prio;
+    {
+        const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
+        p.buf_lds = (g_tune.buf_lds && ib < 2.0e9 && wb < 2.0e9) ? 1 : 0;
+        p.in_bytes = (unsigned)(ib < 4.0e9 ? ib : 0);
+        p.w_bytes = (unsigned)(wb < 4.0e9 ? wb : 0);
+    }
     p.nt_store = (g_tune.nt_store && o.nchw_out && (double)p.M * p.N * 4 >= 4.0e6) ? 1 : 0;
     p.ci_shift = -1;
     for (int sh = 0; sh < 16; ++sh)
@@ -1105,6 +1111,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }

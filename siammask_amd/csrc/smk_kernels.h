@@ -54,6 +54,8 @@ struct ConvParams {
     int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
+    int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
+    unsigned in_bytes, w_bytes;   // extents of the input tensor / weight pack for the SRDs
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
 };
 
@@ -74,6 +76,7 @@ struct Tuning {
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
     int prio = 0;              // consumer-wave priority (see ConvParams::prio)
     int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
+    int buf_lds = 0;           // LDS-DMA through buffer resources instead of flat global addresses
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
