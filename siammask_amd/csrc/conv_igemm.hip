@@ -578,7 +578,7 @@ static int default_stages(int bm, int bn, int kt) {
     return (bm + bn) * kt * 3 <= 160 * 1024 ? 3 : 2;
 }
 
-// Tile choice, fitted to the per-layer micro-benchmark (profiles/r01_v4_convbench_b{1,8,64}_f16.json):
+// Tile choice, fitted to the per-layer micro-benchmark (profiles/r01_v5_convbench_b{8,64}_f16.json, r01_v4_..._b1):
 // the largest tile whose grid still covers the chip about twice (two workgroups per CU hide each
 // other's hand-over bubbles), because the bytes staged through LDS per flop fall with the tile
 // area and the global->LDS path (~20-25 B/clk/CU beside running MFMAs) is what bounds the loop.
@@ -598,8 +598,8 @@ TileChoice choose_tile(const ConvParams &p, int dtype) {
         if (p.Nst <= 64) {
             if (tiles(128, 64) >= 200) { t.bm = 128; t.bn = 64; t.stages = 3; }
             else { t.bm = 64; t.bn = 64; t.stages = 3; }
-        } else if (tiles(256, 128) >= 480 && p.K >= 1024) { t.bm = 256; t.bn = 128; t.stages = 3; }
-        else if (tiles(128, 128) >= 400) { t.bm = 128; t.bn = 128; t.stages = 2; }
+        } else if (tiles(256, 128) >= 900 && p.K >= 2048) { t.bm = 256; t.bn = 128; t.stages = 3; }
+        else if (tiles(128, 128) >= 300) { t.bm = 128; t.bn = 128; t.stages = 2; }
         else if (tiles(64, 128) >= 200) { t.bm = 64; t.bn = 128; t.stages = 3; }
         else { t.bm = 64; t.bn = 64; t.stages = 3; }
     }
