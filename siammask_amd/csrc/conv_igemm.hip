@@ -140,7 +140,7 @@ template <int STAGE_BYTES, int NSTAGE, int EPI, int NWAVES> struct WgPerCu {
     static constexpr int waves_per_simd = wgs * NWAVES / 4;
 };
 #define SMK_NCW (WM * WN * WK)
-#define SMK_EPI (SMK_NCW * 64 * (OUT_MODE == OUT_NCHW_F32 ? 65 : 68) * 4)
+#define SMK_EPI (SMK_NCW * 64 * 68 * 4)
 
 template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
 __global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
@@ -169,7 +169,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
     constexpr int AHEAD = NSTAGE - 1;          // K tiles in flight
     static_assert(AHEAD >= 1 && AHEAD <= 3, "ring depth 2..4");
     constexpr int STAGE_BYTES = (BM + BN) * KT;
-    constexpr int LDE = OUT_MODE == OUT_NCHW_F32 ? 65 : 68;
+    constexpr int LDE = 68;                    // NHWC: row-major [64 rows][68]; NCHW: column-major [64 cols][68]
     constexpr int EPI_BYTES = NCW * 64 * LDE * 4;               // one 64x64 f32 accumulator tile per consumer
     constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -442,7 +442,13 @@ void conv_igemm_kernel(const ConvBatch cb) {
                 for (int r = 0; r < 16; ++r) {
                     int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                     int col = j * 32 + frow;
-                    e[row * LDE + col] = acc[i][j][r];
+                    if (OUT_MODE == OUT_NHWC) {
+                        e[row * LDE + col] = acc[i][j][r];
+                    } else if ((r & 3) == 0) {
+                        // column-major for the NCHW epilogue: r&3 = 0..3 are four consecutive rows
+                        floatx4 v = {acc[i][j][r], acc[i][j][r + 1], acc[i][j][r + 2], acc[i][j][r + 3]};
+                        *(floatx4 *)(e + col * LDE + row) = v;
+                    }
                 }
     }
     __syncthreads();
@@ -486,28 +492,50 @@ void conv_igemm_kernel(const ConvBatch cb) {
             }
         }
     } else {
-        // NCHW f32: threads run along m (contiguous positions of one channel plane); the tensor is
-        // handed to the caller and not re-read on the device: streaming (non-temporal) stores
-        constexpr int CG = NT / BM;          // column groups processed concurrently
-        const int row = tid % BM, cg = tid / BM;
-        const int m = m0 + row;
+        // NCHW f32: each thread owns FOUR consecutive rows (positions of one channel plane) and walks
+        // the columns: 16-byte stores (4 B per lane is store-issue bound: the 63x63 mask logits are
+        // 79 MB per B=8 frame batch).  The tensor is handed to the caller and not re-read on the
+        // device: streaming (non-temporal) stores.
+        typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+        constexpr int RG = BM / 4;           // row groups
+        constexpr int CG = NT / RG;          // columns processed concurrently
+        const int r4 = (tid % RG) * 4, cg = tid / RG;
+        const int m = m0 + r4;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, pos = m - b * hw;
+            const bool vec = (m + 3 < p.M) && (pos + 3 < hw);      // all four rows in one plane
             float *obase = (float *)p.out + (size_t)b * p.N * hw + pos;
-            const float *er = ebase + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
-#pragma unroll 4
+            const float *er = ebase + ((r4 >> 6) * WN * WK) * (64 * LDE) + (r4 & 63);
+#pragma unroll 2
             for (int j = cg; j < BN; j += CG) {
                 const int n = n0 + j;
                 if (n < p.N) {
-                    const float *ec = er + ((j >> 6) * WK) * (64 * LDE) + (j & 63);
-                    float v = ec[0];
+                    const float *ec = er + ((j >> 6) * WK) * (64 * LDE) + (j & 63) * LDE;
+                    floatx4 v = *(const floatx4 *)ec;
 #pragma unroll
-                    for (int q = 1; q < WK; ++q) v += ec[q * (64 * LDE)];
-                    v += bias[n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.nt_store) __builtin_nontemporal_store(v, obase + (size_t)n * hw);
-                    else obase[(size_t)n * hw] = v;
+                    for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(ec + q * (64 * LDE));
+                    const float bn = bias[n];
+                    v[0] += bn; v[1] += bn; v[2] += bn; v[3] += bn;
+                    if (p.relu) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    float *o = obase + (size_t)n * hw;
+                    if (vec) {
+                        float4u vv = {v[0], v[1], v[2], v[3]};
+                        if (p.nt_store) __builtin_nontemporal_store(vv, (float4u *)o);
+                        else *(float4u *)o = vv;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int mq = m + q;
+                            if (mq < p.M) {
+                                const int bq = mq / hw, pq = mq - bq * hw;
+                                ((float *)p.out)[((size_t)bq * p.N + n) * hw + pq] = v[q];
+                            }
+                        }
+                    }
                 }
             }
         }
