@@ -281,3 +281,41 @@ def test_packed_weight_cache(tmp_path):
     m5 = build("sharp", dtype="f32")
     with pytest.raises(_lib.SmkError):
         m5.load_packed(path, device="cuda:0")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_bench_configuration_b8_end_to_end(dtype):
+    """The configuration bench.py measures (sharp + Refine, B=8 streams, fused step graph): at this batch
+    the engine picks the large tiles and the merged launches, which the B<=2 golden cases do not reach.
+    fp32 against the float64 oracle (<=1e-4, argmax position identical per stream), fp16 against the
+    quantisation-aware oracle (<=5e-3)."""
+    from oracle.np_oracle import QuantOracle
+    B = 8
+    z = synth.smooth_image_batch(B, 127, stream0=40)
+    x = synth.smooth_image_batch(B, 255, stream0=40)
+    sd = synth.state_dict("sharp", "synthetic_damped")
+    o = Oracle(sd, "sharp") if dtype == "f32" else QuantOracle(sd, "sharp")
+    o.template(z.astype(np.float64))
+    ocls, oloc, omask = o.track_mask(x.astype(np.float64))
+    twh = np.tile(np.array([[60.0, 80.0]], dtype=np.float32), (B, 1))
+    m = _model("sharp", "synthetic_damped", dtype, True, max_batch=B)
+    m.template(torch.from_numpy(z).cuda())
+    out = m.track_step(torch.from_numpy(x).cuda(), torch.from_numpy(twh).cuda(), refine=True)
+    tol = 1e-4 if dtype == "f32" else 5e-3
+    errs = {"cls": rel_err(out["cls"].cpu().numpy(), ocls), "loc": rel_err(out["loc"].cpu().numpy(), oloc),
+            "mask": rel_err(out["mask"].cpu().numpy(), omask)}
+    box = out["box"].cpu().numpy()
+    pos = []
+    for b in range(B):
+        bid, dy, dx, _ = decode_best(ocls[b], oloc[b], target_sz=(60.0, 80.0), scale_x=1.0)
+        pos.append((dy, dx))
+        if dtype == "f32":
+            assert int(box[b, 7]) == bid, "stream %d: device argmax %d != oracle %d" % (b, int(box[b, 7]), bid)
+    if dtype == "f32":
+        oref = o.track_refine(np.asarray(pos))
+    else:   # refine at the positions the DEVICE decoded (its fp16 argmax may legitimately differ)
+        best = box[:, 7].astype(np.int64)
+        oref = o.track_refine(np.stack([(best % 625) // 25, best % 25], 1))
+    errs["refine"] = rel_err(out["refine"].cpu().numpy(), oref)
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, "B=8 %s: %s (all %s)" % (dtype, bad, errs)
