@@ -98,6 +98,8 @@ struct PackedConv {
     int group_rows = 0;      // rows per group
     int groups = 1;
     int Ci = 0, k = 1, K = 0, Kpad = 0;
+    int kw = 0;              // horizontal taps when != k (pixel-pair stem)
+    int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
 };
 
 static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
@@ -278,6 +280,9 @@ static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPa
     return 0;
 }
 
+static ConvPart bnpart(const std::string &conv, const std::string &bn) { return ConvPart{conv + ".weight", bn, ""}; }
+static ConvPart biaspart(const std::string &conv) { return ConvPart{conv + ".weight", "", conv + ".bias"}; }
+
 // refine_model.deconv: ConvTranspose2d(256, 32, 15, 15) on a 1x1 input == GEMM with
 // N = 15*15*32 ordered (ky, kx, co) so that the result is the NHWC tensor [15][15][32]
 static int pack_deconv(smk_ctx *c) {
@@ -303,15 +308,42 @@ static int pack_deconv(smk_ctx *c) {
     return 0;
 }
 
+// features.conv1 (7x7 s2 p0, 3 -> 64) on the pixel-pair input layout [H][ceil(W/2)][2 px x 4 ch]:
+// a 7 x 4 convolution over pixel pairs (vertical stride 2, horizontal stride 1 pair), K = 7*4*8 = 224
+// instead of 7*7*8 = 392 with the channel-padded layout; the 8th pixel and the 4th channel have zero weights
+static int pack_stem(smk_ctx *c) {
+    const std::string f = "features.features.";
+    const HostTensor *w = find_w(c, f + "conv1.weight");
+    if (!w) return fail(SMK_E_WEIGHT, "missing weight %sconv1.weight", f.c_str());
+    if (w->shape.size() != 4 || w->shape[0] != 64 || w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7)
+        return fail(SMK_E_WEIGHT, "weight %sconv1.weight has wrong shape", f.c_str());
+    std::vector<double> scale, shift;
+    CHK(fold(c, bnpart(f + "conv1", f + "bn1"), 64, scale, shift));
+    PackedConv pc;
+    pc.Ci = 8; pc.k = 7; pc.kw = 4; pc.K = 7 * 4 * 8; pc.Kpad = rup(pc.K, KPAD_ALIGN); pc.alg_k = 3 * 7 * 7;
+    pc.groups = 1; pc.N = 64; pc.group_rows = pc.rows = rup(64, NPAD_ALIGN);
+    std::vector<float> rows((size_t)pc.rows * pc.Kpad, 0.f), bias(pc.rows, 0.f);
+    for (int n = 0; n < 64; ++n) {
+        for (int ky = 0; ky < 7; ++ky)
+            for (int kx = 0; kx < 7; ++kx)
+                for (int ci = 0; ci < 3; ++ci) {
+                    const double v = (double)w->data[(((size_t)n * 3 + ci) * 7 + ky) * 7 + kx] * scale[n];
+                    rows[(size_t)n * pc.Kpad + (size_t)(ky * 4 + kx / 2) * 8 + (kx & 1) * 4 + ci] = (float)v;
+                }
+        bias[n] = (float)shift[n];
+    }
+    CHK(upload_packed(pc, rows, bias, c->dtype));
+    c->conv["stem"] = pc;
+    return 0;
+}
+
 static const int STAGE_PLANES[3] = {64, 128, 256};
 static const int STAGE_BLOCKS[3] = {3, 4, 6};
 
-static ConvPart bnpart(const std::string &conv, const std::string &bn) { return ConvPart{conv + ".weight", bn, ""}; }
-static ConvPart biaspart(const std::string &conv) { return ConvPart{conv + ".weight", "", conv + ".bias"}; }
 
 static int build_weights(smk_ctx *c) {
     const std::string f = "features.features.";
-    CHK(pack_conv(c, "stem", {bnpart(f + "conv1", f + "bn1")}, 3, 64, 7, false));
+    CHK(pack_stem(c));
     int inplanes = 64;
     for (int s = 0; s < 3; ++s) {
         const int planes = STAGE_PLANES[s];
@@ -429,6 +461,7 @@ static Act act(smk_ctx *c, const char *name, int H, int W, int C) {
 // ---------------------------------------------------------------------------------------------
 struct ConvOpt {
     int stride = 1, pad = 0, dil = 1, relu = 0;
+    int stride_x = 0;         // horizontal stride when != stride (pixel-pair stem)
     const Act *res = nullptr;
     int res_mode = RES_NONE;
     int res_coff = 0;
@@ -464,10 +497,12 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.org_y = o.org_y; p.org_x = o.org_x;
     p.pos_mul = o.pos_mul; p.pos_add = o.pos_add;
     p.ups = o.ups ? 1 : 0;
-    p.kh = p.kw = pc.k;
+    p.kh = pc.k;
+    p.kw = pc.kw ? pc.kw : pc.k;
     p.stride = o.stride; p.pad = o.pad; p.dil = o.dil;
-    p.Ho = (p.Hl + 2 * o.pad - o.dil * (pc.k - 1) - 1) / o.stride + 1;
-    p.Wo = (p.Wl + 2 * o.pad - o.dil * (pc.k - 1) - 1) / o.stride + 1;
+    p.stride_x = o.stride_x ? o.stride_x : o.stride;
+    p.Ho = (p.Hl + 2 * o.pad - o.dil * (p.kh - 1) - 1) / p.stride + 1;
+    p.Wo = (p.Wl + 2 * o.pad - o.dil * (p.kw - 1) - 1) / p.stride_x + 1;
     p.K = pc.K; p.Kpad = pc.Kpad;
     p.N = o.n_override ? o.n_override : pc.N;
     p.M = B * p.Ho * p.Wo;
@@ -546,7 +581,7 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     const TileChoice t = tile_from_code(o.tile_code, p, c->dtype);
     const int ng = p.groups > 0 ? p.groups : 1;
     // algorithmic work: 2*M*N*K_real flops; bytes = activations read once + weights + output written once
-    const double kreal = (double)p.kh * p.kw * p.Ci;
+    const double kreal = it->second.alg_k ? (double)it->second.alg_k : (double)p.kh * p.kw * p.Ci;
     const double flop = 2.0 * p.M * (double)p.N * kreal * ng;
     const size_t es = esize(c->dtype);
     const double in_bytes = (double)B * (p.ups ? p.Hs * p.Ws : (double)p.Hl * p.Wl) * p.Ci * es * ng;
@@ -596,15 +631,15 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
     const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
     const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
     const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
-    Act xin = act(c, "xin", S, S, 8);
-    CvtInParams ci{x, xin.p, B, 3, S, S, 8};
+    Act xin = act(c, "xin", S, (S + 1) / 2, 8);            // pixel-pair layout (see pack_stem)
+    CvtInParams ci{x, xin.p, B, 3, S, S, 8, 1};
     {
         ProfScope ps(c, s, "cvt_in", "cvt_in", 0.0, (double)B * S * S * (3 * 4 + 8 * esize(c->dtype)));
         if (launch_cvt_in(ci, c->dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     }
     Act p0 = act(c, "p0", s0, s0, 64);
     ConvOpt o;
-    o.stride = 2; o.relu = 1;
+    o.stride = 2; o.stride_x = 1; o.relu = 1;
     CHK(run_conv(c, "stem", xin, &p0, B, o, s));
     Act x1 = act(c, "x1", s1, s1, 64);
     PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1};
@@ -851,7 +886,7 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 0; }
+int smk_version(void) { return (1 << 16) | 1; }
 
 const char *smk_last_error(void) { return g_err.c_str(); }
 
@@ -949,7 +984,7 @@ struct PackHeader {
 };
 struct PackEntry {
     char id[24];
-    int32_t N, rows, group_rows, groups, Ci, k, K, Kpad;
+    int32_t N, rows, group_rows, groups, Ci, k, K, Kpad, kw, alg_k;
 };
 
 static size_t packed_bytes(const smk_ctx *c) {
@@ -987,7 +1022,7 @@ int smk_export_packed(smk_ctx *c, void *host_buf, uint64_t capacity) {
         if (kv.first.size() >= sizeof(en.id)) return fail(SMK_E_STATE, "internal: conv id too long");
         memcpy(en.id, kv.first.c_str(), kv.first.size());
         en.N = pc.N; en.rows = pc.rows; en.group_rows = pc.group_rows; en.groups = pc.groups;
-        en.Ci = pc.Ci; en.k = pc.k; en.K = pc.K; en.Kpad = pc.Kpad;
+        en.Ci = pc.Ci; en.k = pc.k; en.K = pc.K; en.Kpad = pc.Kpad; en.kw = pc.kw; en.alg_k = pc.alg_k;
         memcpy(o, &en, sizeof(en)); o += sizeof(en);
         const size_t wb = (size_t)pc.rows * pc.Kpad * esize(c->dtype), bb = (size_t)pc.rows * 4;
         HIPCHK(hipMemcpy(o, pc.w, wb, hipMemcpyDeviceToHost)); o += wb;
@@ -1025,7 +1060,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
         if (p + wb + bb > end) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated data of %s", en.id);
         PackedConv pc;
         pc.N = en.N; pc.rows = en.rows; pc.group_rows = en.group_rows; pc.groups = en.groups;
-        pc.Ci = en.Ci; pc.k = en.k; pc.K = en.K; pc.Kpad = en.Kpad;
+        pc.Ci = en.Ci; pc.k = en.k; pc.K = en.K; pc.Kpad = en.Kpad; pc.kw = en.kw; pc.alg_k = en.alg_k;
         HIPCHK(hipMalloc(&pc.w, wb));
         HIPCHK(hipMemcpy(pc.w, p, wb, hipMemcpyHostToDevice)); p += wb;
         HIPCHK(hipMalloc((void **)&pc.bias, bb));
@@ -1318,7 +1353,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
     const size_t es = esize(dtype);
     CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
-    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C};
+    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C, 0};
     if (launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     int *pos_dev = nullptr;
     if (pos_host) {
@@ -1336,7 +1371,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         if (nchw) return fail(SMK_E_ARG, "residual is not supported with the NCHW epilogue");
         res = out;
         CHK(tmp.alloc(&res.p, (size_t)g->B * Ho * Wo * out.C * es));
-        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, out.C};
+        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, out.C, 0};
         if (launch_cvt_in(cr, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
         o.res = &res; o.res_mode = g->res_mode;
     }
@@ -1386,7 +1421,7 @@ int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, in
     CHK(tmp.alloc(&x, (size_t)B * H * W * C * es));
     CHK(tmp.alloc(&k, (size_t)B * kh * kw * C * es));
     CHK(tmp.alloc(&y, (size_t)B * Ho * Wo * C * es));
-    CvtInParams cx{x_dev, x, B, C, H, W, C}, ck{k_dev, k, B, C, kh, kw, C};
+    CvtInParams cx{x_dev, x, B, C, H, W, C, 0}, ck{k_dev, k, B, C, kh, kw, C, 0};
     if (launch_cvt_in(cx, dtype, s) || launch_cvt_in(ck, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     XcorrParams xp{x, k, y, B, H, W, kh, kw, Ho, Wo, C, C};
     if (launch_xcorr(xp, dtype, s)) return fail(SMK_E_HIP, "xcorr launch failed");
@@ -1406,7 +1441,7 @@ int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int 
     void *x, *y;
     CHK(tmp.alloc(&x, (size_t)B * H * W * C * es));
     CHK(tmp.alloc(&y, (size_t)B * Ho * Wo * C * es));
-    CvtInParams cx{x_dev, x, B, C, H, W, C};
+    CvtInParams cx{x_dev, x, B, C, H, W, C, 0};
     if (launch_cvt_in(cx, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     PoolParams pp{x, y, B, H, W, C, Ho, Wo};
     if (launch_maxpool(pp, dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");

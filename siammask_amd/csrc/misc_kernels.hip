@@ -204,7 +204,42 @@ __global__ void cvt_in_kernel(const CvtInParams p) {
     }
 }
 
+// stem input: two horizontally adjacent pixels x (3 channels + 1 zero) per 16-byte (f16) vector, so that
+// the 7x7 stride-2 stem becomes a 7 x 4 "pixel-pair" convolution with K = 224 instead of 7*7*8 = 392
+template <typename T>
+__global__ void cvt_in_pairs_kernel(const CvtInParams p) {
+    const int wp = (p.W + 1) / 2;
+    const long total = (long)p.B * p.H * wp;
+    const long hw = (long)p.H * p.W;
+    T *out = (T *)p.out;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int xp = (int)(idx % wp);
+        const long t = idx / wp;
+        const int y = (int)(t % p.H), b = (int)(t / p.H);
+        T v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int px = 2 * xp + (e >> 2), c = e & 3;
+            v[e] = (px < p.W && c < p.C) ? (T)p.in[((size_t)b * p.C + c) * hw + (size_t)y * p.W + px] : (T)0.f;
+        }
+        T *o = out + (size_t)idx * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[e];
+    }
+}
+
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream) {
+    if (p.pairs) {
+        const long total = (long)p.B * p.H * ((p.W + 1) / 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 16384) blocks = 16384;
+        if (blocks < 1) blocks = 1;
+        hipStream_t s = (hipStream_t)stream;
+        if (dtype == DT_F16) hipLaunchKernelGGL(cvt_in_pairs_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(cvt_in_pairs_kernel<float>, dim3(blocks), dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     const long total = (long)p.B * p.H * p.W * (p.Cpad / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;

@@ -37,7 +37,8 @@ struct ConvParams {
     int pos_mul, pos_add;  // origin += pos*pos_mul + pos_add when pos != nullptr
     int ups;               // 1: logical image = nearest-upsampled storage (sy = ly*Hs/Hl)
     int Ho, Wo;
-    int kh, kw, stride, pad, dil;
+    int kh, kw, stride, pad, dil;   // stride = vertical stride; horizontal stride is stride_x
+    int stride_x;
     int K, Kpad;
     int N;                 // real output channels
     int Nst;               // channels stored in NHWC mode (multiple of 4, >= N, zeros above N)
@@ -107,7 +108,7 @@ SMK_HD RowInfo row_info(const ConvParams &p, int m, const int *pos) {
     int oy = rem / p.Wo;
     int ox = rem - oy * p.Wo;
     r.ly0 = oy * p.stride - p.pad;
-    r.lx0 = ox * p.stride - p.pad;
+    r.lx0 = ox * p.stride_x - p.pad;
     r.oy_org = p.org_y;
     r.ox_org = p.org_x;
     if (pos) {
@@ -143,7 +144,8 @@ struct XcorrParams {
 
 struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
 
-struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; };  // NCHW f32 -> NHWC dtype
+struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; };  // NCHW f32 -> NHWC dtype
+// pairs = 1 (stem input, C <= 4): [B][H][ceil(W/2)][2 pixels x 4 channels], missing pixel / channel = 0
 struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; };  // NHWC dtype -> NCHW f32
 
 // on-device restatement of the host decode of tools/test.py:205-254 (one workgroup per stream)
