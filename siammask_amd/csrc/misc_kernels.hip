@@ -39,13 +39,14 @@ template <> struct P2<_Float16> {
 // each thread owns a channel pair and one half-row strip of outputs and slides the kw-wide
 // window along x in registers (each staged value is read from LDS once per tap row).
 // ------------------------------------------------------------------------------------------
-constexpr int XC_CH = 64;      // channels per workgroup
 constexpr int XC_BR = 5;       // output rows per workgroup
 constexpr int XC_SW = 13;      // max outputs per thread strip (half of a 25-wide row)
 constexpr int XC_KMAX = 5;     // max taps per row
-constexpr int XC_THREADS = 32 * XC_BR * 2;
+constexpr int XC_THREADS = 32 * XC_BR * 2;   // upper bound (64-channel workgroups)
 
-template <typename T>
+// XC_CH = channels per workgroup (64 or 32): 32 doubles the number of workgroups, whose load / compute /
+// store phases then overlap better on a CU (this kernel is latency-, not bandwidth-limited at B=8)
+template <typename T, int XC_CH>
 __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     constexpr int VE = 16 / (int)sizeof(T);
@@ -60,22 +61,24 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
     const T *k = (const T *)p.k;
 
     const int nvx = rows_in * p.W * VPP;
-    for (int v = threadIdx.x; v < nvx; v += XC_THREADS) {
+    const int nthr = blockDim.x;
+    for (int v = threadIdx.x; v < nvx; v += nthr) {
         const int pix = v / VPP, q = v - pix * VPP;
         const int r = pix / p.W, col = pix - r * p.W;
         const size_t g = ((size_t)(b * p.H + i0 + r) * p.W + col) * p.Cs + c0 + q * VE;
         *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = *(const uint4 *)(x + g);
     }
     const int nvk = p.kh * p.kw * VPP;
-    for (int v = threadIdx.x; v < nvk; v += XC_THREADS) {
+    for (int v = threadIdx.x; v < nvk; v += nthr) {
         const int tap = v / VPP, q = v - tap * VPP;
         const size_t g = ((size_t)b * p.kh * p.kw + tap) * p.Cs + c0 + q * VE;
         *(uint4 *)(sk + (size_t)tap * XC_CH + q * VE) = *(const uint4 *)(k + g);
     }
     __syncthreads();
 
-    const int cp = threadIdx.x & 31;                 // channel pair
-    const int strip = threadIdx.x >> 5;              // 0 .. 2*BR-1
+    constexpr int NCP = XC_CH / 2;                   // channel pairs per workgroup
+    const int cp = threadIdx.x % NCP;                // channel pair
+    const int strip = threadIdx.x / NCP;             // 0 .. 2*BR-1 (threads beyond that idle when XC_CH = 32 ... see launch)
     const int ri = strip >> 1, half = strip & 1;
     if (ri >= rows_out) return;
     const int wfirst = (p.Wo + 1) / 2;               // 13 of 25
@@ -116,15 +119,21 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
         }
 }
 
-int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
-    if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % XC_CH != 0) return -1;
+template <typename T, int CH>
+static void launch_xcorr_t(const XcorrParams &p, hipStream_t s) {
     const int bands = (p.Ho + XC_BR - 1) / XC_BR;
-    dim3 grid(bands, p.C / XC_CH, p.B);
-    const size_t esz = dtype == DT_F16 ? 2 : 4;
-    const size_t lds = ((size_t)(XC_BR + XC_KMAX - 1) * p.W + XC_KMAX * XC_KMAX) * XC_CH * esz;
+    dim3 grid(bands, p.C / CH, p.B);
+    const size_t lds = ((size_t)(XC_BR + XC_KMAX - 1) * p.W + XC_KMAX * XC_KMAX) * CH * sizeof(T);
+    // (CH/2 channel pairs) x (2*BR half-row strips) threads
+    hipLaunchKernelGGL((dw_xcorr_kernel<T, CH>), grid, dim3((CH / 2) * XC_BR * 2), lds, s, p);
+}
+
+int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
+    if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % 64 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DT_F16) hipLaunchKernelGGL(dw_xcorr_kernel<_Float16>, grid, dim3(XC_THREADS), lds, s, p);
-    else hipLaunchKernelGGL(dw_xcorr_kernel<float>, grid, dim3(XC_THREADS), lds, s, p);
+    const bool c32 = g_tune.xc_ch == 32;
+    if (dtype == DT_F16) { if (c32) launch_xcorr_t<_Float16, 32>(p, s); else launch_xcorr_t<_Float16, 64>(p, s); }
+    else { if (c32) launch_xcorr_t<float, 32>(p, s); else launch_xcorr_t<float, 64>(p, s); }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
