@@ -613,12 +613,10 @@ static int default_stages(int bm, int bn, int kt) {
 TileChoice choose_tile(const ConvParams &p, int dtype) {
     (void)dtype;
     TileChoice t;
-    t.wk8 = 0;
     if (g_tune.force_tile) {
-        static const int tb[8][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 128}, {64, 128}};
+        static const int tb[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
         t.bm = tb[g_tune.force_tile][0];
         t.bn = tb[g_tune.force_tile][1];
-        t.wk8 = g_tune.force_tile >= 6;
         t.stages = default_stages(t.bm, t.bn, default_kt(t.bm, t.bn));
     } else {
         const long ng = p.groups > 0 ? p.groups : 1;
@@ -636,7 +634,6 @@ TileChoice choose_tile(const ConvParams &p, int dtype) {
     t.kt = g_tune.kt ? g_tune.kt : default_kt(t.bm, t.bn);
     if (t.bm == 64 && t.bn == 64) t.kt = 256;
     if (t.bm == 256) t.kt = 128;
-    if (t.wk8) t.kt = t.bm == 128 ? 128 : 256;
     if (g_tune.stages) t.stages = g_tune.stages;
     return t;
 }
@@ -679,10 +676,6 @@ template <typename T, int OM>
 static int launch_tiles(ConvBatch &cb, TileChoice t, hipStream_t s) {
     const bool k256 = t.kt == 256;
     if (t.bm == 256) return launch_stages<T, 4, 2, 1, 128, OM>(cb, t.stages, s);
-    // eight consumers on a 128x128 / 64x128 tile (K split inside the workgroup): one workgroup per CU with
-    // two consumer waves per SIMD and a deep ring
-    if (t.wk8 && t.bm == 128 && t.bn == 128) return launch_stages<T, 2, 2, 2, 128, OM>(cb, t.stages, s);
-    if (t.wk8 && t.bm == 64 && t.bn == 128) return launch_stages<T, 1, 2, 4, 256, OM>(cb, t.stages, s);
     if (t.bm == 128 && t.bn == 128)
         return k256 ? launch_stages<T, 2, 2, 1, 256, OM>(cb, t.stages, s) : launch_stages<T, 2, 2, 1, 128, OM>(cb, t.stages, s);
     if (t.bm == 128 && t.bn == 64)

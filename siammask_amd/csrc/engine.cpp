@@ -558,18 +558,16 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
 // (0 auto, 1 128 B, 2 256 B), bits 6-7 ring depth (0 auto, 1..3 -> 2..4 stages)
 static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
     TileChoice t = choose_tile(p, dtype);
-    static const int tb[8][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 128}, {64, 128}};
+    static const int tb[6][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
     const int tile = code & 15, kt = (code >> 4) & 3, st = (code >> 6) & 3;
-    if (tile >= 1 && tile <= 7) {
+    if (tile >= 1 && tile <= 5) {
         t.bm = tb[tile][0]; t.bn = tb[tile][1];
-        t.wk8 = tile >= 6;
         t.kt = (t.bm == 64 && t.bn == 64) ? 256 : 128;
         t.stages = (t.bm == 128 && t.bn == 128) ? 2 : 3;
     }
     if (kt) t.kt = kt == 2 ? 256 : 128;
     if (t.bm == 64 && t.bn == 64) t.kt = 256;
     if (t.bm == 256) t.kt = 128;
-    if (t.wk8) t.kt = t.bm == 128 ? 128 : 256;
     if (st) t.stages = st + 1;
     return t;
 }
@@ -590,7 +588,7 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     const double out_bytes = (double)p.M * p.N * ng * (p.out_mode == OUT_NCHW_F32 ? 4 : es);
     const double bytes = in_bytes + out_bytes + (double)p.N * kreal * es * ng + (p.res ? (double)p.M * p.N * es : 0.0);
     char kn[64];
-    snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d%s,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.wk8 ? "k8" : "", t.stages,
+    snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
     int rc;
     {
@@ -1143,7 +1141,7 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
 int smk_tune(const char *key, int value) {
     if (!key) return fail(SMK_E_ARG, "smk_tune: key is NULL");
     if (!strcmp(key, "xcd_mode")) g_tune.xcd_mode = value;
-    else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "force_tile 0..7"); g_tune.force_tile = value; }
+    else if (!strcmp(key, "force_tile")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "force_tile 0..5"); g_tune.force_tile = value; }
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }

@@ -182,7 +182,7 @@ struct PasteParams {
 };
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
-struct TileChoice { int bm, bn, kt, stages, wk8; };   // wk8: eight consumers, K split inside the workgroup
+struct TileChoice { int bm, bn, kt, stages; };
 TileChoice choose_tile(const ConvParams &p, int dtype);
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
 int launch_conv_mfma_batch(ConvBatch &cb, int dtype, TileChoice t, void *stream);

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3}
-TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5, (128, 128, 8): 6, (64, 128, 8): 7}
+TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5}
 
 
 def _chk_cuda(*ts):

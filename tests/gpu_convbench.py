@@ -48,7 +48,7 @@ LAYERS = {
     "v0.2":        (16, 61, 4, 3, 1, 1, 1, 1, 0, None, 0, 0, 1),
 }
 CONFIGS = [((128, 128), 128), ((128, 128), 256), ((128, 64), 128), ((128, 64), 256),
-           ((64, 128), 128), ((64, 128), 256), ((64, 64), 256), ((256, 128), 128), ((128, 128, 8), 128), ((64, 128, 8), 256)]
+           ((64, 128), 128), ((64, 128), 256), ((64, 64), 256), ((256, 128), 128)]
 
 
 def main():
@@ -71,7 +71,7 @@ def main():
                 for stages in (2, 3, 4):
                     if (tile[0] + tile[1]) * kt * stages > 160 * 1024:
                         continue
-                    key = "%dx%d%s/%d/s%d" % (tile[0], tile[1], "k8" if len(tile) > 2 else "", kt, stages)
+                    key = "%dx%d/%d/s%d" % (tile[0], tile[1], kt, stages)
                     try:
                         runs[key] = round(ops.bench_conv(B * bm, cin, hw, hw, cout, k, st, pad, dil, dtype=dtype,
                                                          tile=tile, kt=kt, stages=stages, res=bool(r), nchw=bool(nchw),
