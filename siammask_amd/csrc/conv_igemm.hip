@@ -103,20 +103,6 @@ template <int NP> __device__ __forceinline__ void wait_tiles(int n_tiles) {
     else wait_vmcnt<2 * NP>();
 }
 
-// producer/consumer hand-over through LDS counters (p.sync_flags): bounded polling, so that a protocol
-// error shows up as a wrong result and never as a hung GPU
-__device__ __forceinline__ void poll_ge(volatile int *f, int target) {
-    for (int spin = 0; spin < (1 << 18); ++spin) {
-        const int v = __builtin_amdgcn_readfirstlane(*f);
-        if (v >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void signal_inc(int *f, int lane) {
-    if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // XOR swizzle of the 16-byte slot inside an LDS row (SPR slots per row): makes the ds_read_b128
 // fragment reads (32 consecutive rows, same logical slot) bank-conflict free.
 //   SPR = 8  (128-byte rows, two rows per 256-byte bank line): (row>>1)&7
@@ -186,8 +172,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
     constexpr int LDE = 68;                    // NHWC: row-major [64 rows][68]; NCHW: column-major [64 cols][68]
     constexpr int EPI_BYTES = NCW * 64 * LDE * 4;               // one 64x64 f32 accumulator tile per consumer
     constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES + 64];   // + hand-over counters
-    int *full_f = (int *)(smem + LDS_BYTES), *empty_f = full_f + 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,11 +202,6 @@ void conv_igemm_kernel(const ConvBatch cb) {
     const int nk = (p.K + BK - 1) / BK;
 
     floatx16 acc[2][2];                // consumers only
-    const bool flags = p.sync_flags != 0;
-    if (flags) {
-        if (tid < 16) full_f[tid] = 0;
-        __syncthreads();
-    }
 
     if (wave >= NCW) {
         // =========================== PRODUCER: gather + LDS-DMA ===============================
@@ -327,27 +307,6 @@ void conv_igemm_kernel(const ConvBatch cb) {
             }
         };
 
-        if (flags) {
-            // counters instead of the all-wave barrier: a tile is issued as soon as the consumers have
-            // released its slot, and AHEAD tiles of this wave stay in flight (steady LDS-DMA queue)
-            int slot = 0;
-            for (int t = 0; t < nk; ++t) {
-                if (t >= NSTAGE) poll_ge(&empty_f[slot], NCW * (t / NSTAGE));
-                set_tile(t);
-                issue_tile(t, slot);
-                if (t >= AHEAD) {
-                    wait_vmcnt<AHEAD * NP>();                       // my pieces of tile t-AHEAD have landed
-                    int ds = slot - AHEAD;
-                    if (ds < 0) ds += NSTAGE;
-                    signal_inc(&full_f[ds], lane);
-                }
-                if (++slot == NSTAGE) slot = 0;
-            }
-            for (int t = nk > AHEAD ? nk - AHEAD : 0; t < nk; ++t) {
-                wait_tiles<NP>(nk - 1 - t);
-                signal_inc(&full_f[t % NSTAGE], lane);
-            }
-        } else {
 #pragma unroll
         for (int tt = 0; tt < AHEAD; ++tt)
             if (tt < nk) {
@@ -368,7 +327,6 @@ void conv_igemm_kernel(const ConvBatch cb) {
                 issue_tile(kt + AHEAD, islot);
             }
             if (++islot == NSTAGE) islot = 0;
-        }
         }
     } else {
         // =========================== CONSUMER: LDS fragments + MFMA ===========================
@@ -402,8 +360,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
         if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
         else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
         else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
-        if (flags) poll_ge(&full_f[0], 4);
-        else __builtin_amdgcn_s_barrier();                 // barrier(0): tile 0 is complete
+        __builtin_amdgcn_s_barrier();                      // barrier(0): tile 0 is complete
         asm volatile("" ::: "memory");
         read_frags(0, 0, fa[0], fb[0]);
         // Issue order inside a k-step (pinned with sched_barrier):
@@ -438,12 +395,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
                     if (kt + 1 < nk) {
                         // all my LDS reads of tile kt are complete (the MFMAs above consumed them)
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (flags) {
-                            signal_inc(&empty_f[cur], lane);                       // slot of tile kt is free
-                            poll_ge(&full_f[nxt], 4 * ((kt + 1) / NSTAGE + 1));    // tile kt+1 is complete
-                        } else {
-                            __builtin_amdgcn_s_barrier();      // barrier(kt+1)
-                        }
+                        __builtin_amdgcn_s_barrier();          // barrier(kt+1)
                         asm volatile("" ::: "memory");
                         read_frags(nxt, 0, fa[0], fb[0]);
                     }

@@ -531,7 +531,6 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     }
     p.xcd_mode = g_tune.xcd_mode;
     p.prio = g_tune.prio;
-    p.sync_flags = g_tune.sync_flags;
     {
         const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
         p.buf_lds = (g_tune.buf_lds && ib < 2.0e9 && wb < 2.0e9) ? 1 : 0;
@@ -1147,7 +1146,6 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
-    else if (!strcmp(key, "sync_flags")) g_tune.sync_flags = value != 0;
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;

@@ -55,7 +55,6 @@ struct ConvParams {
     int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
-    int sync_flags;        // producer/consumer hand-over through LDS counters instead of s_barrier
     int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
     unsigned in_bytes, w_bytes;   // extents of the input tensor / weight pack for the SRDs
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
@@ -78,7 +77,6 @@ struct Tuning {
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
     int prio = 0;              // consumer-wave priority (see ConvParams::prio)
     int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
-    int sync_flags = 0;        // conv kernel: LDS-counter hand-over instead of the per-K-tile barrier
     int xc_ch = 64;            // dw_xcorr: channels per workgroup (64 or 32)
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
