@@ -542,6 +542,317 @@ void conv_igemm_kernel(const ConvBatch cb) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT> -- 3x3 stride-1 convolutions with the activation patch
+// staged ONCE per channel chunk and shared by all nine taps.
+//
+// The implicit GEMM above re-stages the A rows for every tap (9 x BM x 128 B per 64-channel chunk).
+// Here the K loop runs chunk-major (chunk, kh, kw): for a chunk the producers load the tile's input
+// FOOTPRINT -- every padded-input pixel any of its BM output pixels touches, as rows of 128 bytes in
+// padded row-major order -- and the consumers read tap (kh, kw) of output row r at LDS row
+//     arow[r] + kh*dil*Wp + kw*dil          (arow[r] = oy*Wp + ox - q0, Wp = padded input width)
+// i.e. the nine taps are nine constant row offsets into the same patch.  A tile covers BM consecutive
+// output pixels of ONE image (tiles do not straddle images), so the footprint is a contiguous range of
+// the padded-linear pixel index: BM + a few row wraps + 2*dil*(Wp+1) rows instead of 9*BM.
+// Weights need the chunk-major K order (PackedConv::w_halo).  One patch buffer (single: a new chunk
+// starts with an extra barrier) + an NSLOT-deep weight ring (counted vmcnt inside a chunk) keep the LDS at
+// <= 76 KB, two workgroups per CU.
+// NHWC epilogue only.  p.buf_lds must be set (SRD range check supplies all zero padding).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT>
+__global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p) {
+    static_assert(WM * WN * WK == 4 && (WK == 1 || WK == 2), "four consumers, K split <= 2");
+    typedef Traits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    constexpr int NCW = 4, NT = 512;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int KT = 128;                          // bytes of channels per chunk and per weight K tile
+    constexpr int CH = KT / (int)sizeof(T);          // channels per chunk
+    constexpr int RB = BN / 32, NRND = AROWS / 32;   // LDS-DMA pieces per producer thread: weights per tap / patch
+    constexpr int NKS = 4 / WK;
+    constexpr int A_BYTES = AROWS * KT, W_STAGE = BN * KT;
+    constexpr int LDE = 68;
+    constexpr int EPI_BYTES = NCW * 64 * LDE * 4;
+    constexpr int LDS_BYTES = CMax<A_BYTES + NSLOT * W_STAGE, EPI_BYTES>::v;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    unsigned char *sA = smem, *sW = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *bias = p.bias;
+    const int howo = p.Ho * p.Wo, Wp = p.Wl + 2 * p.pad;
+    const int tpi = (howo + BM - 1) / BM;            // tiles per image
+    const int tilesN = (p.Nst + BN - 1) / BN;
+    int t = blockIdx.x;
+    if (p.xcd_mode != 0) {                           // XCD-contiguous tm-major order (see the kernel above)
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int x = t & 7, j = t >> 3;
+        t = x * q + (x < r ? x : r) + j;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    const int b = tm / tpi, ml0 = (tm - b * tpi) * BM;
+    const int n0 = tn * BN;
+    const int oy0 = ml0 / p.Wo, ox0 = ml0 - oy0 * p.Wo;
+    const int q0 = oy0 * Wp + ox0;                   // padded-linear index of output row 0 at tap (0,0)
+    const int nvalid = howo - ml0 < BM ? howo - ml0 : BM;
+    const int nch = p.Ci / CH, nk = nch * 9;
+
+    floatx16 acc[2][2];
+    if (wave >= NCW) {
+        // =========================== PRODUCER ===================================================
+        const int ptid = tid - NCW * 64, pw = wave - NCW;
+        const int lrow = ptid >> 3;
+        const int slot = (ptid & 7) ^ swz<8>(lrow);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, p.w_bytes, 0x00020000);
+        constexpr unsigned OOB = 0x7ffff000u;
+        int org_y = p.org_y, org_x = p.org_x;
+        if (p.pos) {
+            org_y += p.pos[2 * b + 0] * p.pos_mul + p.pos_add;
+            org_x += p.pos[2 * b + 1] * p.pos_mul + p.pos_add;
+        }
+        const int mlast = ml0 + nvalid - 1;
+        const int oyl = mlast / p.Wo, oxl = mlast - oyl * p.Wo;
+        const int nrows = oyl * Wp + oxl - q0 + 2 * p.dil * Wp + 2 * p.dil + 1;
+        unsigned aoff[NRND];
+#pragma unroll
+        for (int i = 0; i < NRND; ++i) {
+            const int j = lrow + 32 * i;
+            const int q = q0 + j;
+            const int iyp = q / Wp, ixp = q - iyp * Wp;
+            const int ly = iyp - p.pad, lx = ixp - p.pad;
+            const int sy = ly + org_y, sx = lx + org_x;
+            const bool ok = (j < nrows) & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl) &
+                            ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
+            const long off = (((long)(b * p.Hs + sy) * p.Ws + sx) * p.Cs + p.cin_off) * (long)sizeof(T) + slot * 16;
+            aoff[i] = ok ? (unsigned)off : OOB;
+        }
+        unsigned wofs[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) wofs[i] = (unsigned)((size_t)(n0 + lrow + 32 * i) * p.Kpad * sizeof(T)) + slot * 16;
+        auto issue_A = [&](int c) {
+            unsigned char *d = sA + pw * 1024;
+#pragma unroll
+            for (int i = 0; i < NRND; ++i)
+                if (i * 32 < nrows)                        // (wave-uniform) rounds beyond the footprint are skipped
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(d + i * 4096), 16,
+                                                             (int)(aoff[i] == OOB ? OOB : aoff[i] + (unsigned)c * KT), 0, 0, 0);
+        };
+        int wslot = 0;                                 // ring slot of the next weight tile to issue
+        auto issue_W = [&](int kt) {
+            unsigned char *d = sW + wslot * W_STAGE + pw * 1024;
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(d + i * 4096), 16, (int)wofs[i], kt * KT, 0, 0);
+            wslot = wslot + 1 == NSLOT ? 0 : wslot + 1;
+        };
+        issue_A(0);
+#pragma unroll
+        for (int j = 0; j < NSLOT - 1; ++j)
+            if (j < nk) issue_W(j);
+        int tap = 0;                                   // tap index of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt landed?  In flight behind it: tiles kt+1 .. kt+NSLOT-2 (and, when kt opens a chunk, the
+            // patch, which is the youngest load -> drain everything)
+            if (tap == 0 || kt + NSLOT - 2 >= nk) wait_vmcnt<0>();
+            else wait_vmcnt<RB * (NSLOT - 2)>();
+            __builtin_amdgcn_s_barrier();              // barrier(kt): tile kt complete, tile kt-1 released
+            asm volatile("" ::: "memory");
+            if (kt + NSLOT - 1 < nk) issue_W(kt + NSLOT - 1);
+            if (++tap == 9) {                          // tile kt+1 opens a chunk: the patch is still read by tile kt
+                tap = 0;
+                if (kt + 1 < nk) {
+                    __builtin_amdgcn_s_barrier();      // barrier(x): consumers are done with the patch
+                    asm volatile("" ::: "memory");
+                    issue_A((kt + 1) / 9);
+                }
+            }
+        }
+    } else {
+        // =========================== CONSUMER ===================================================
+        const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int frow = lane & 31, fhalf = lane >> 5;
+        int arow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = ml0 + wm * 64 + i * 32 + frow;
+            const int oy = ml / p.Wo, ox = ml - oy * p.Wo;
+            arow[i] = ml < howo ? oy * Wp + ox - q0 : 0;
+        }
+        const int fsw = swz<8>(frow);
+        const int b_row_off = (wn * 64 + frow) * KT;
+        frag_t fa[2][2], fb[2][2];
+        auto read_frags = [&](int wso, int toff, int s, frag_t (&a)[2], frag_t (&bq)[2]) {
+            const int sl = (s * WK + wk) * 2 + fhalf;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = arow[i] + toff;
+                a[i] = *(const frag_t *)(sA + ra * KT + ((sl ^ ((ra >> 1) & 7)) << 4));
+            }
+            const unsigned char *sb = sW + wso + b_row_off + ((sl ^ fsw) << 4);
+            bq[0] = *(const frag_t *)sb;
+            bq[1] = *(const frag_t *)(sb + 32 * KT);
+        };
+        auto mma_part = [&](int par, int q0_, int q1_) {
+#pragma unroll
+            for (int q = q0_; q < q1_; ++q) TR::mma(acc[q >> 1][q & 1], fa[par][q >> 1], fb[par][q & 1]);
+        };
+        auto tap_off = [&](int tap) {
+            const int kh = (tap * 11) >> 5;            // tap / 3 for tap < 9
+            return (kh * Wp + (tap - 3 * kh)) * p.dil;
+        };
+        __builtin_amdgcn_s_barrier();                  // barrier(0)
+        asm volatile("" ::: "memory");
+        int tap = 0, toff = 0, wso = 0;                // wso: byte offset of tile kt's weight slot
+        read_frags(0, 0, 0, fa[0], fb[0]);
+        for (int kt = 0; kt < nk; ++kt) {
+            int tapn = tap + 1;
+            if (tapn == 9) tapn = 0;
+            const int toffn = tap_off(tapn);
+            const int wson = wso + W_STAGE == NSLOT * W_STAGE ? 0 : wso + W_STAGE;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                if (s == 0) {
+                    mma_part(0, 0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(wso, toff, 1, fa[1], fb[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(0, 1, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (s + 1 < NKS) {
+                    read_frags(wso, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(s & 1, 0, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    mma_part(s & 1, 0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 1 < nk) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (tapn == 0) {
+                            __builtin_amdgcn_s_barrier();      // barrier(x): the patch may be replaced
+                            asm volatile("" ::: "memory");
+                        }
+                        __builtin_amdgcn_s_barrier();          // barrier(kt+1)
+                        asm volatile("" ::: "memory");
+                        read_frags(wson, toffn, 0, fa[0], fb[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(s & 1, 2, 4);
+                }
+            }
+            tap = tapn;
+            toff = toffn;
+            wso = wson;
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (NHWC): accumulators -> LDS -> K-group sum -> bias / residual / ReLU -> 16-byte stores
+    constexpr int EV = TR::EV;
+    constexpr int LPR = BN / EV, RPP = NT / LPR, NPASS = (BM + RPP - 1) / RPP;
+    const int c4 = (tid % LPR) * EV, r0 = tid / LPR;
+    const int m0 = b * howo + ml0;
+    float rv[NPASS][EV];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int q = 0; q < EV; ++q) rv[ps][q] = 0.f;
+    if (p.res_mode != RES_NONE && n0 + c4 < p.Nst) {
+        const T *res = (const T *)p.res;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = ps * RPP + r0;
+            if (row < nvalid) TR::loadv(res + (size_t)(m0 + row) * p.res_Cs + p.res_coff + n0 + c4, rv[ps]);
+        }
+    }
+    if (wave < NCW) {
+        float *e = (float *)smem + wave * (64 * LDE);
+        const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    e[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * LDE + j * 32 + frow] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int n = n0 + c4;
+    if (n < p.Nst) {
+        const float *ebase = (const float *)smem;
+        float bv[EV];
+#pragma unroll
+        for (int q = 0; q < EV; q += 4) {
+            const floatx4 b4 = *(const floatx4 *)(bias + n + q);
+            bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
+        }
+        T *out = (T *)p.out;
+        const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = ps * RPP + r0;
+            if (row < nvalid) {
+                const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
+                float v[EV];
+#pragma unroll
+                for (int q = 0; q < EV; q += 4) {
+                    floatx4 x = *(const floatx4 *)(er + q);
+#pragma unroll
+                    for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (64 * LDE) + q);
+                    v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
+                }
+#pragma unroll
+                for (int q = 0; q < EV; ++q) {
+                    float x = v[q] + bv[q];
+                    if (p.res_mode == RES_PRE_RELU) x += rv[ps][q];
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.res_mode == RES_POST_RELU) x += rv[ps][q];
+                    v[q] = x;
+                }
+                TR::storev(out + (size_t)(m0 + row) * p.Cos + p.cout_off + n, v);
+            }
+        }
+    }
+}
+
+// host side: eligibility + launch.  Returns 1 when the geometry does not fit (caller falls back to the
+// generic kernel), 0 on success, < 0 on launch errors.  p.wgt must be the chunk-major weight pack.
+template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT>
+static int launch_halo_t(const ConvParams &p, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int howo = p.Ho * p.Wo, Wp = p.Wl + 2 * p.pad;
+    const int tpi = (howo + BM - 1) / BM;
+    int worst = 0;
+    for (int tl = 0; tl < tpi; ++tl) {
+        const int ml0 = tl * BM, nv = howo - ml0 < BM ? howo - ml0 : BM;
+        const int oy0 = ml0 / p.Wo, ox0 = ml0 % p.Wo, ml = ml0 + nv - 1, oyl = ml / p.Wo, oxl = ml % p.Wo;
+        const int rows = oyl * Wp + oxl - (oy0 * Wp + ox0) + 2 * p.dil * Wp + 2 * p.dil + 1;
+        if (rows > worst) worst = rows;
+    }
+    if (worst > AROWS) return 1;
+    dim3 grid(p.B * tpi * ((p.Nst + BN - 1) / BN));
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT>), grid, dim3(512), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = dtype == DT_F16 ? 64 : 32;
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.stride_x != 1 || p.ups || p.groups > 1 || p.Ci % ch != 0 ||
+        p.out_mode != OUT_NHWC || !p.buf_lds || p.Wo != p.Wl + 2 * p.pad - 2 * p.dil)
+        return 1;
+    if (dtype == DT_F16)
+        return bm == 128 ? launch_halo_t<_Float16, 2, 2, 1, 320, 2>(p, s) : launch_halo_t<_Float16, 1, 2, 2, 224, 3>(p, s);
+    return bm == 128 ? launch_halo_t<float, 2, 2, 1, 320, 2>(p, s) : launch_halo_t<float, 1, 2, 2, 224, 3>(p, s);
+}
+
 // ---- naive reference kernel: one thread per (m, 4 channels); same params, same packing ----
 template <typename T>
 __global__ void conv_naive_kernel(const ConvParams p) {

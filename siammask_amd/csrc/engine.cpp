@@ -92,6 +92,7 @@ struct ConvPart {
 
 struct PackedConv {
     void *w = nullptr;       // device [rows][Kpad] dtype
+    void *w_halo = nullptr;  // same weights, K ordered (chunk, kh, kw, c in chunk) for conv3x3_halo_kernel (3x3 only)
     float *bias = nullptr;   // device [rows] f32
     int N = 0;               // real output channels per group
     int rows = 0;            // total rows (all groups), multiple of NPAD_ALIGN
@@ -130,6 +131,28 @@ static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, con
     }
     HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * 4));
     HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// chunk-major copy of a 3x3 pack: k = (tap*Ci + c)  ->  k' = ((c / CH)*9 + tap)*CH + c % CH
+static int upload_halo_pack(PackedConv &pc, const std::vector<float> &rows_f32, int dtype) {
+    const int CH = dtype == DT_F16 ? 64 : 32;
+    if (pc.k != 3 || pc.kw != 0 || pc.Ci % CH != 0) return 0;
+    std::vector<float> hp(rows_f32.size(), 0.f);
+    for (int n = 0; n < pc.rows; ++n)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < pc.Ci; ++ci)
+                hp[(size_t)n * pc.Kpad + (size_t)((ci / CH) * 9 + tap) * CH + ci % CH] =
+                    rows_f32[(size_t)n * pc.Kpad + (size_t)tap * pc.Ci + ci];
+    const size_t cnt = hp.size();
+    HIPCHK(hipMalloc(&pc.w_halo, cnt * esize(dtype)));
+    if (dtype == DT_F16) {
+        std::vector<_Float16> h(cnt);
+        for (size_t i = 0; i < cnt; ++i) h[i] = (_Float16)hp[i];
+        HIPCHK(hipMemcpy(pc.w_halo, h.data(), cnt * 2, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(pc.w_halo, hp.data(), cnt * 4, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -200,6 +223,7 @@ struct ProfScope {
         idx = (int)c->prof_recs.size() - 1;
     }
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, s); }
+    void cancel() { if (idx >= 0 && idx == (int)c->prof_recs.size() - 1) { c->prof_recs.pop_back(); c->prof_pool_next -= 2; } idx = -1; }
 };
 
 // make `to` wait for everything enqueued so far on `from` (captured as a graph dependency)
@@ -276,6 +300,7 @@ static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPa
         for (int n = 0; n < Cout; ++n) bias[row0 + n] = (float)shift[n];
     }
     CHK(upload_packed(pc, rows, bias, c->dtype));
+    if (!grouped) CHK(upload_halo_pack(pc, rows, c->dtype));
     c->conv[id] = pc;
     return 0;
 }
@@ -479,6 +504,7 @@ struct ConvOpt {
     float *nchw_out = nullptr;
     int algo_naive = 0;
     int tile_code = 0;
+    int halo = 0;             // 128 / 64: force the halo kernel with this BM (per-op tests)
 };
 
 static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, const Act *out, int B,
@@ -572,6 +598,19 @@ static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
     return t;
 }
 
+// conv3x3_halo_kernel or the generic kernel?  Returns the halo workgroup height (128 / 64) or 0.
+// Measured on MI355X (profiles/r01_v6_halo_ab.txt): the halo kernel wins on every 3x3 stride-1 layer of the
+// path except the long-K wide-N projection (l3.0.downsample, K=4608 N=1024), where the 256x128 generic tile
+// amortises the weight stream better; BM=128 once the launch has >= 300 such tiles, else BM=64.
+static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt &o) {
+    const int mode = o.halo ? o.halo : g_tune.halo;
+    if (!mode || !pc.w_halo || p.out_mode != OUT_NHWC || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ups) return 0;
+    if (mode != 1) return mode;
+    if (p.Ci * 9 > 2304 && p.Nst >= 512) return 0;
+    const long tiles128 = (long)p.B * ((p.Ho * p.Wo + 127) / 128) * ((p.Nst + 127) / 128);
+    return tiles128 >= 300 ? 128 : 64;
+}
+
 static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, int B, const ConvOpt &o,
                     hipStream_t s) {
     auto it = c->conv.find(id);
@@ -590,8 +629,19 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     char kn[64];
     snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
-    int rc;
-    {
+    int rc = 1;
+    const int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o);
+    if (bm) {
+        // 3x3 stride-1: the activation patch is staged once per channel chunk and shared by the nine taps
+        ConvParams ph = p;
+        ph.wgt = it->second.w_halo;
+        char kh_[64];
+        snprintf(kh_, sizeof(kh_), "conv3x3_halo<%s,%dx128>", dtname(c->dtype), bm);
+        ProfScope ps(c, s, id, kh_, flop, bytes);
+        rc = launch_conv_halo(ph, c->dtype, bm, s);
+        if (rc == 1) ps.cancel();
+    }
+    if (rc == 1) {
         ProfScope ps(c, s, id, o.algo_naive ? "conv_naive" : kn, flop, bytes);
         rc = o.algo_naive ? launch_conv_naive(p, c->dtype, s) : launch_conv_mfma(p, c->dtype, t, s);
     }
@@ -605,16 +655,23 @@ struct ConvJob { const char *id; const Act *in; const Act *out; ConvOpt o; };
 
 static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, int lead, hipStream_t s) {
     if (jobs.empty() || (int)jobs.size() > CONV_BATCH_MAX) return fail(SMK_E_ARG, "internal: bad conv job count");
-    if (c->prof || jobs.size() == 1 || !g_tune.merge) {        // per-layer attribution while profiling
-        for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
-        return 0;
-    }
     ConvBatch cb;
     cb.n = (int)jobs.size();
+    // merging pays while the single problems under-fill the chip; once every halo-eligible member is a full
+    // launch of BM=128 tiles on its own, separate halo launches are faster than the merged generic one
+    bool split_for_halo = g_tune.halo != 0;
+    int n_halo = 0;
     for (int i = 0; i < cb.n; ++i) {
         auto it = c->conv.find(jobs[i].id);
         if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", jobs[i].id);
         CHK(conv_params(c, it->second, *jobs[i].in, jobs[i].out, B, jobs[i].o, cb.p[i]));
+        const int bm = halo_choice(it->second, cb.p[i], jobs[i].o);
+        if (bm) ++n_halo;
+        if (bm == 64 || (bm == 0 && cb.p[i].kh == 3)) split_for_halo = false;
+    }
+    if (c->prof || cb.n == 1 || !g_tune.merge || (split_for_halo && n_halo)) {   // per-layer attribution while profiling
+        for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
+        return 0;
     }
     const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], c->dtype);
     if (launch_conv_mfma_batch(cb, c->dtype, t, s))
@@ -934,7 +991,7 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf) hipFree(kv.second);
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
@@ -965,7 +1022,7 @@ int smk_finalize_weights(smk_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
     c->conv.clear();
     int rc = build_weights(c);
     if (rc) return rc;
@@ -1046,7 +1103,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
     c->conv.clear();
     c->finalized = false;
     for (int i = 0; i < h.n_conv; ++i) {
@@ -1062,7 +1119,14 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
         pc.N = en.N; pc.rows = en.rows; pc.group_rows = en.group_rows; pc.groups = en.groups;
         pc.Ci = en.Ci; pc.k = en.k; pc.K = en.K; pc.Kpad = en.Kpad; pc.kw = en.kw; pc.alg_k = en.alg_k;
         HIPCHK(hipMalloc(&pc.w, wb));
-        HIPCHK(hipMemcpy(pc.w, p, wb, hipMemcpyHostToDevice)); p += wb;
+        HIPCHK(hipMemcpy(pc.w, p, wb, hipMemcpyHostToDevice));
+        if (pc.groups == 1) {                      // chunk-major copy for the halo kernel (derived, not stored)
+            std::vector<float> rf((size_t)en.rows * en.Kpad);
+            if (c->dtype == DT_F16) { const _Float16 *h = (const _Float16 *)p; for (size_t i = 0; i < rf.size(); ++i) rf[i] = (float)h[i]; }
+            else memcpy(rf.data(), p, wb);
+            CHK(upload_halo_pack(pc, rf, c->dtype));
+        }
+        p += wb;
         HIPCHK(hipMalloc((void **)&pc.bias, bb));
         HIPCHK(hipMemcpy(pc.bias, p, bb, hipMemcpyHostToDevice)); p += bb;
         c->conv[en.id] = pc;
@@ -1146,6 +1210,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
@@ -1366,6 +1431,12 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     o.tile_code = (algo >> 8) & 0xff;
     o.algo_naive = (mode == 1 || mode == 3);
     const bool nchw = (mode == 2 || mode == 3);
+    if (mode == 4) {                                   // halo kernel (3x3 stride 1), BM from the tile code
+        o.halo = (o.tile_code & 15) == 1 ? 128 : 64;
+        CHK(upload_halo_pack(pc, rows, dtype));
+        if (!pc.w_halo) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry is not eligible for the halo kernel");
+        tmp.v.push_back(pc.w_halo);
+    }
     Act out, res;
     out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8);
     if (res_dev && g->res_mode) {
@@ -1387,8 +1458,16 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         CHK(tmp.alloc(&out.p, (size_t)g->B * Ho * Wo * out.C * es));
         CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
     }
-    int rc = o.algo_naive ? launch_conv_naive(p, dtype, s)
+    int rc;
+    if (o.halo) {
+        ConvParams ph = p;
+        ph.wgt = pc.w_halo;
+        rc = launch_conv_halo(ph, dtype, o.halo, s);
+        if (rc == 1) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry is not eligible for the halo kernel");
+    } else {
+        rc = o.algo_naive ? launch_conv_naive(p, dtype, s)
                           : launch_conv_mfma(p, dtype, tile_from_code(o.tile_code, p, dtype), s);
+    }
     if (rc) return fail(SMK_E_HIP, "conv launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (!nchw) {
         CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0};
@@ -1565,14 +1644,16 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
     ConvParams p;
     CHK(conv_params(&fake, pc, in, mode == 2 ? nullptr : &out, g->B, o, p));
     const TileChoice t = tile_from_code(o.tile_code, p, dtype);
+    const int halo_bm = mode == 4 ? ((o.tile_code & 15) == 1 ? 128 : 64) : 0;     // timing only: K order is irrelevant
+    auto launch = [&]() { return halo_bm ? launch_conv_halo(p, dtype, halo_bm, s) : launch_conv_mfma(p, dtype, t, s); };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i)
-        if (launch_conv_mfma(p, dtype, t, s)) return fail(SMK_E_HIP, "conv launch failed");
+        if (launch()) return fail(SMK_E_HIP, "conv launch failed or geometry not eligible");
     HIPCHK(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i)
-        if (launch_conv_mfma(p, dtype, t, s)) return fail(SMK_E_HIP, "conv launch failed");
+        if (launch()) return fail(SMK_E_HIP, "conv launch failed");
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -77,6 +77,7 @@ struct Tuning {
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
     int prio = 0;              // consumer-wave priority (see ConvParams::prio)
     int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
+    int halo = 1;              // 3x3 stride-1 convolutions through conv3x3_halo_kernel (0 off, 128 / 64 = BM)
     int xc_ch = 64;            // dw_xcorr: channels per workgroup (64 or 32)
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
@@ -187,6 +188,9 @@ TileChoice choose_tile(const ConvParams &p, int dtype);
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
 int launch_conv_mfma_batch(ConvBatch &cb, int dtype, TileChoice t, void *stream);
 int launch_conv_naive(const ConvParams &p, int dtype, void *stream);
+// 3x3 stride-1 convolution with the activation patch shared by the nine taps (chunk-major weight pack);
+// returns 1 when the geometry is not eligible
+int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);

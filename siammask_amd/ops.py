@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3}
+ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4}
 TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5}
 
 
@@ -88,7 +88,7 @@ def maxpool3x3s2(x, dtype="f32"):
 
 
 def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=None, kt=0, stages=0,
-               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50):
+               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50, halo=False):
     """average microseconds per launch of the MFMA conv kernel on this geometry (smk_bench_conv)"""
     g = _lib.ConvGeom()
     g.B, g.Cin, g.H, g.W = B, Cin, H, W
@@ -98,7 +98,7 @@ def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=
     if win is not None:
         g.win, g.Hl, g.Wl = 1, win[0], win[1]
     us = ctypes.c_float(0.0)
-    code = (2 if nchw else 0) | (tile_code(tile, kt, stages) << 8)
+    code = (4 if halo else (2 if nchw else 0)) | (tile_code(tile, kt, stages) << 8)
     _lib.check(_lib.lib().smk_bench_conv(_lib.DTYPE[dtype], code, ctypes.byref(g), int(bool(res)), iters,
                                          ctypes.byref(us), _lib.current_stream_ptr()))
     return us.value

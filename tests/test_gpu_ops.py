@@ -69,6 +69,52 @@ def test_conv_classes(cfg, dtype):
     assert not bad, "conv %s %s: %s (all: %s)" % (cfg, dtype, bad, errs)
 
 
+HALO_CASES = [
+    # cin, cout, pad, dil, hw, B   (3x3 stride 1; Cin a multiple of the 128-byte channel chunk)
+    (64, 64, 1, 1, 31, 2),        # l1/l2-style 3x3 p1
+    (128, 96, 1, 1, 33, 1),       # odd N, odd size
+    (256, 256, 2, 2, 31, 1),      # l3 dilated
+    (256, 128, 0, 1, 31, 2),      # conv_search: p0 (29x29 out)
+    (64, 32, 1, 1, 63, 1),        # wide image: many row wraps per tile
+    (512, 256, 1, 1, 15, 3),      # small image, long K, tiles end inside the image
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cfg", HALO_CASES)
+def test_conv3x3_halo_kernel(cfg, dtype):
+    """conv3x3_halo_kernel (activation patch shared by the nine taps, chunk-major weight pack) against the
+    oracle, both workgroup shapes, with bias + ReLU + residual."""
+    ops = _ops()
+    cin, cout, pad, dil, hw, B = cfg
+    rng = np.random.default_rng(hash(cfg) & 0xffff)
+    x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, 3, 3) / np.sqrt(cin * 9), _rand(rng, cout)
+    ho = hw + 2 * pad - 2 * dil
+    res = _rand(rng, B, cout, ho, ho)
+    ref = np.maximum(O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64), 1, pad, dil) + _q(res, dtype), 0)
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
+    for tile in ((128, 128), (64, 128)):
+        y = ops.conv2d(xd, w, b, 1, pad, dil, relu=True, res=rd, res_mode=1, dtype=dtype, algo="halo", tile=tile)
+        e = rel_err(y.cpu().numpy(), ref)
+        assert e <= TOL[dtype], "halo %s %s tile %s: %.3e" % (cfg, dtype, tile, e)
+
+
+def test_conv3x3_halo_windows():
+    """per-stream windows (Refine v*.0: F.pad + slice at a position) through the halo kernel"""
+    ops = _ops()
+    rng = np.random.default_rng(6)
+    f = _rand(rng, 3, 64, 31, 31)
+    w = _rand(rng, 32, 64, 3, 3) / 24
+    pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
+    for dtype in ("f32", "f16"):
+        fp = np.pad(_q(f, dtype), ((0, 0), (0, 0), (4, 4), (4, 4)))
+        ref = np.concatenate([O.conv2d(fp[b:b + 1, :, y:y + 15, x:x + 15], _q(w, dtype), None, 1, 1, 1)
+                              for b, (y, x) in enumerate(pos)])
+        y = ops.conv2d(torch.from_numpy(f).cuda(), w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4, dtype=dtype,
+                       algo="halo", tile=(64, 128))
+        assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_conv_epilogues(dtype):
     """bias + residual (before / after ReLU) + ReLU, as used by Bottleneck (resnet.py:99-101)
