@@ -282,8 +282,11 @@ class QuantOracle(Oracle):
       * tensors handed back to the caller (cls, loc, mask, refine logits) are fp32: not rounded.
     Same call surface as ``Oracle``."""
 
-    def __init__(self, sd, variant="sharp"):
+    def __init__(self, sd, variant="sharp", refine_sum_in_h=True):
         super(QuantOracle, self).__init__(sd, variant, np.float64)
+        # which of Refine's two branch outputs is stored (rounded) before the sum: True = v*.2 (the default
+        # device path, refine_chain.hip), False = h*.2 (the per-layer path, SMK_TUNE=chain=0)
+        self.refine_sum_in_h = refine_sum_in_h
 
     def _fold(self, conv, bn=None):
         w = self.sd[conv + ".weight"]
@@ -371,6 +374,10 @@ class QuantOracle(Oracle):
             ha = self._fused(out, r + h + ".0", pad=1, act=True)
             hb = self._fused(ha, r + h + ".2", pad=1, act=True)
             va = self._fused(pf, r + v + ".0", pad=1, act=True)
+            if self.refine_sum_in_h:      # device default (refine_chain.hip): v*.2 stored, added after h*.2's ReLU
+                vb = self._fused(va, r + v + ".2", pad=1, act=True)
+                hb = self._fused(ha, r + h + ".2", pad=1, act=True, res=vb, res_after_relu=True)
+                return self._fused(upsample_nearest(hb, size), r + post, pad=1, store=store)
             s = self._fused(va, r + v + ".2", pad=1, act=True, res=hb, res_after_relu=True)
             return self._fused(upsample_nearest(s, size), r + post, pad=1, store=store)
 

@@ -871,6 +871,41 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
     }
     Act d = act(c, "rf_d", 15, 15, 32);
+    if (c->dtype == DT_F16 && g_tune.chain && !par) {
+        // fp16: v*.2 in one merged launch (they only depend on v*.0), then the nine sequential convolutions
+        // h2 -> post0 -> h1 -> post1 -> h0 -> post2 as ONE launch with the activations in LDS (refine_chain.hip)
+        if (!merged) {
+            CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
+            CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
+            CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
+        }
+        Act V2 = act(c, "rf_s2", 15, 15, 32), V1 = act(c, "rf_s1", 31, 31, 16), V0 = act(c, "rf_s0", 61, 61, 8);
+        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3}, {"v1.2", &v1a, &V1, r3}, {"v0.2", &v0a, &V0, r3}}, B, 0, s));
+        static const char *ids[9] = {"h2.0", "h2.2", "post0", "h1.0", "h1.2", "post1", "h0.0", "h0.2", "post2"};
+        static const int geo[9][3] = {{225, 32, 32}, {225, 32, 32}, {961, 32, 16}, {961, 16, 16}, {961, 16, 16},
+                                      {3721, 16, 4}, {3721, 4, 4}, {3721, 4, 4}, {16129, 4, 1}};   // pixels, Cin, Cout
+        RefineChainParams rp;
+        double flop = 0.0, wbytes = 0.0;
+        for (int i = 0; i < 9; ++i) {
+            auto it = c->conv.find(ids[i]);
+            if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", ids[i]);
+            const PackedConv &pc = it->second;
+            if (pc.k != 3 || pc.groups != 1 || pc.Ci < geo[i][1] || pc.N != geo[i][2])
+                return fail(SMK_E_STATE, "internal: conv %s does not have the Refine geometry", ids[i]);
+            rp.L[i] = RefineChainLayer{pc.w, pc.bias, pc.Kpad, pc.Ci};
+            flop += 2.0 * B * geo[i][0] * 9.0 * geo[i][1] * geo[i][2];
+            wbytes += 2.0 * 9.0 * geo[i][1] * geo[i][2];
+        }
+        rp.d = d.p;
+        rp.v2 = V2.p; rp.v1 = V1.p; rp.v0 = V0.p;
+        rp.v2_cs = V2.C; rp.v1_cs = V1.C; rp.v0_cs = V0.C;
+        rp.out = out;
+        rp.B = B;
+        ProfScope ps(c, s, "refine_chain", "refine_chain", flop,
+                     B * (2.0 * (7200 + 225 * 32 + 961 * 16 + 3721 * 4) + 4.0 * 16129) + wbytes);
+        if (launch_refine_chain(rp, s)) return fail(SMK_E_HIP, "refine_chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return 0;
+    }
     // stage 2 @15x15                                             (:150)
     Act h2a = act(c, "rf_h2a", 15, 15, 32), h2b = act(c, "rf_h2b", 15, 15, 32);
     CHK(run_conv(c, "h2.0", d, &h2a, B, r3, s));
@@ -1210,6 +1245,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;

@@ -77,7 +77,9 @@ struct Tuning {
     int kt = 0;                // K tile bytes: 0 auto, 128 or 256
     int prio = 0;              // consumer-wave priority (see ConvParams::prio)
     int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
-    int halo = 1;              // 3x3 stride-1 convolutions through conv3x3_halo_kernel (0 off, 128 / 64 = BM)
+    int halo = 1;              // 3x3 stride-1 convolutions through conv3x3_halo_kernel (0 off, 1 per-shape choice,
+                               // 128 / 64 force that workgroup height)
+    int chain = 1;             // fp16: Refine's sequential tail as one launch (refine_chain_kernel)
     int xc_ch = 64;            // dw_xcorr: channels per workgroup (64 or 32)
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
@@ -191,6 +193,21 @@ int launch_conv_naive(const ConvParams &p, int dtype, void *stream);
 // 3x3 stride-1 convolution with the activation patch shared by the nine taps (chunk-major weight pack);
 // returns 1 when the geometry is not eligible
 int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);
+// the sequential tail of Refine (h2, post0, h1, post1, h0, post2) as one launch, fp16 only (refine_chain.hip)
+struct RefineChainLayer {
+    const void *w;         // packed weights [rows][Kpad] fp16, K = (tap, channel of a Ci-channel image)
+    const float *bias;
+    int Kpad, Ci;
+};
+struct RefineChainParams {
+    const void *d;                        // deconv output [B][15*15][32]
+    const void *v2, *v1, *v0;             // ReLU(v*.2(...)) NHWC: [B][15*15][v2_cs], [B][31*31][v1_cs], [B][61*61][v0_cs]
+    int v2_cs, v1_cs, v0_cs;
+    RefineChainLayer L[9];                // h2.0 h2.2 post0 h1.0 h1.2 post1 h0.0 h0.2 post2
+    float *out;                           // [B][127*127] f32
+    int B;
+};
+int launch_refine_chain(const RefineChainParams &p, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);

@@ -10,7 +10,7 @@ knob, vals = sys.argv[1], [int(v) for v in sys.argv[2].split(",")]
 SHAPES = {"l3.0.ds": (512, 31, 1024, 3, 1, 1, 1), "l3.c2": (256, 31, 256, 3, 1, 2, 2), "l3.c3": (256, 31, 1024, 1, 1, 0, 1),
           "l3.c1": (1024, 31, 256, 1, 1, 0, 1), "l1.c2": (64, 63, 64, 3, 1, 1, 1), "l2.0.ds": (256, 63, 512, 3, 2, 0, 1),
           "stem": (3, 255, 64, 7, 2, 0, 1)}
-for B in (8, 64):
+for B in (() if os.environ.get('AB_E2E_ONLY') else (8, 64)):
     for name, (cin, hw, cout, k, st, pad, dil) in SHAPES.items():
         row = []
         for rep in range(2):

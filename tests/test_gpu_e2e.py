@@ -150,6 +150,38 @@ def test_fp16_tight_gate_vs_quant_oracle(variant):
     assert not bad, "fp16 tight gate %s: %s (all %s)" % (variant, bad, errs)
 
 
+def test_refine_chain_equals_layer_path():
+    """fp16: Refine's tail as ONE launch (refine_chain_kernel, activations in LDS) against the same nine
+    convolutions as separate launches of the generic kernel, and against the fp64 oracle.  Positions at the
+    score-map corners exercise the zero-padded feature windows."""
+    from siammask_amd import _lib
+    fixture = "synthetic_damped"
+    z = synth.smooth_image_batch(3, 127, stream0=21)
+    x = synth.smooth_image_batch(3, 255, stream0=21)
+    pos = np.array([[0, 0], [24, 24], [12, 7]], dtype=np.int32)
+    got = {}
+    try:
+        for chain in (0, 1):
+            _lib.tune(chain=chain)
+            m = _model("sharp", fixture, "f16", True)
+            m.template(torch.from_numpy(z).cuda())
+            m.track_mask(torch.from_numpy(x).cuda())
+            got[chain] = m.track_refine(pos).cpu().numpy()
+    finally:
+        _lib.tune(chain=1)
+    o = Oracle(synth.state_dict("sharp", fixture), "sharp")
+    o.template(z.astype(np.float64))
+    o.track_mask(x.astype(np.float64))
+    ref = o.track_refine(pos)
+    errs = {"chain_vs_layers": rel_err(got[1], got[0]), "chain_vs_oracle": rel_err(got[1], ref),
+            "layers_vs_oracle": rel_err(got[0], ref)}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "e2e_refine_chain.json"), "w") as f:
+        json.dump(errs, f, indent=1)
+    assert errs["chain_vs_layers"] <= 5e-3, errs          # same rounding points, different summation order
+    assert errs["chain_vs_oracle"] <= 1e-2, errs          # the loose fp16 gate of the refine logits
+
+
 def test_batch_invariance_and_order_errors():
     """B=2 equals two B=1 runs; call-order and batch-mismatch errors surface as exceptions."""
     g = load_golden("sharp_damped_b2")
