@@ -14,9 +14,10 @@ scaling, no data-path collective) and gathers boxes/masks with one RCCL all_gath
 of the K frames, inside the timed region.
 
 Prints ONE JSON line (driver contract) with two extra objects:
-  roofline     -- dominant kernel family (conv_igemm, the MFMA implicit GEMM): algorithmic
-                  FLOPs of its launches / their HIP-event durations, measured live on the
-                  launch stream by the library's per-launch profiler (smk_profile);
+  roofline     -- dominant kernel family (the MFMA implicit-GEMM convolutions: conv_igemm_kernel and
+                  its 3x3 patch-sharing sibling conv3x3_halo_kernel): algorithmic FLOPs of its
+                  launches / their HIP-event durations, measured live on the launch stream by the
+                  library's per-launch profiler (smk_profile);
   cpu_baseline -- the CPU port of the reference op sequence (oracle/torch_port.py) timed on
                   this host's cores on a bounded sample (rank 0, N=1 only).
 """
@@ -161,6 +162,9 @@ def timed_run(w, steps, warmup, world, gather):
     return dt
 
 
+CONV_FAMILY = "conv_igemm+conv3x3_halo"
+
+
 def roofline(w, steps=3):
     """Per-launch HIP-event timing of every kernel (library profiler, eager launches on the
     current stream) -> achieved TFLOP/s of the dominant kernel family."""
@@ -173,6 +177,7 @@ def roofline(w, steps=3):
     fam = {}
     for r in recs:
         k = r["kernel"].split("<")[0]
+        k = CONV_FAMILY if k in ("conv_igemm", "conv3x3_halo") else k     # the two MFMA implicit-GEMM conv kernels
         f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0})
         f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["bytes"] += r["bytes"]; f["calls"] += r["calls"]
     total_ms = sum(f["ms"] for f in fam.values())
@@ -180,7 +185,7 @@ def roofline(w, steps=3):
     d = fam[dom]
     peak = PEAK_TFLOPS[w.dtype]
     achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    heavy = max((r for r in recs if r["kernel"].startswith("conv_igemm")), key=lambda r: r["ms"])
+    heavy = max((r for r in recs if r["kernel"].startswith(("conv_igemm", "conv3x3_halo"))), key=lambda r: r["ms"])
     xc = fam.get("dw_xcorr")
     out = {
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -200,7 +205,7 @@ def roofline(w, steps=3):
         try:
             t = json.load(open(pmc))
             out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
-            out["traffic_note"] = "bytes per conv_igemm launch; %s; %s" % (t["source"], t["correction"])
+            out["traffic_note"] = "bytes per launch of the conv kernels (conv_igemm, conv3x3_halo); %s; %s" % (t["source"], t["correction"])
         except Exception:  # noqa: BLE001
             pass
     out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))

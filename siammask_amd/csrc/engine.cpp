@@ -103,6 +103,8 @@ struct PackedConv {
     int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
 };
 
+constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 4 + 8 * 4 + 4;     // decode_kernel's cross-workgroup scratch
+
 static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
 
 // host-side packing of ONE weight tensor [Cout][Cin][k][k] (already scaled) into rows of a
@@ -183,6 +185,7 @@ struct smk_ctx {
     std::map<std::string, void *> buf;
     std::map<std::string, size_t> buf_elems;  // per item
     int *pos_dev = nullptr;
+    void *dec_scratch = nullptr;     // decode: per-stream winners of the A workgroups + arrival counters
 
     // decode (tools/test.py:205-254 on device)
     float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
@@ -471,6 +474,8 @@ static int build_arena(smk_ctx *c) {
     }
     HIPCHK(hipMalloc((void **)&c->pos_dev, sizeof(int) * 2 * c->maxB));
     HIPCHK(hipMemset(c->pos_dev, 0, sizeof(int) * 2 * c->maxB));
+    HIPCHK(hipMalloc(&c->dec_scratch, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
+    HIPCHK(hipMemset(c->dec_scratch, 0, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
     return 0;
 }
 
@@ -602,10 +607,11 @@ static TileChoice tile_from_code(int code, const ConvParams &p, int dtype) {
 // Measured on MI355X (profiles/r01_v6_halo_ab.txt): the halo kernel wins on every 3x3 stride-1 layer of the
 // path except the long-K wide-N projection (l3.0.downsample, K=4608 N=1024), where the 256x128 generic tile
 // amortises the weight stream better; BM=128 once the launch has >= 300 such tiles, else BM=64.
-static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt &o) {
+static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt &o, int dtype) {
     const int mode = o.halo ? o.halo : g_tune.halo;
     if (!mode || !pc.w_halo || p.out_mode != OUT_NHWC || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.ups) return 0;
     if (mode != 1) return mode;
+    if (dtype != DT_F16) return 0;            // fp32 (32-channel chunks, 32x32x2 MFMA): measured slower, 1.33 vs 1.09 ms at B=1
     if (p.Ci * 9 > 2304 && p.Nst >= 512) return 0;
     const long tiles128 = (long)p.B * ((p.Ho * p.Wo + 127) / 128) * ((p.Nst + 127) / 128);
     return tiles128 >= 300 ? 128 : 64;
@@ -630,7 +636,7 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
     int rc = 1;
-    const int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o);
+    const int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
     if (bm) {
         // 3x3 stride-1: the activation patch is staged once per channel chunk and shared by the nine taps
         ConvParams ph = p;
@@ -665,7 +671,7 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
         auto it = c->conv.find(jobs[i].id);
         if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", jobs[i].id);
         CHK(conv_params(c, it->second, *jobs[i].in, jobs[i].out, B, jobs[i].o, cb.p[i]));
-        const int bm = halo_choice(it->second, cb.p[i], jobs[i].o);
+        const int bm = halo_choice(it->second, cb.p[i], jobs[i].o, c->dtype);
         if (bm) ++n_halo;
         if (bm == 64 || (bm == 0 && cb.p[i].kh == 3)) split_for_halo = false;
     }
@@ -901,9 +907,29 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         rp.v2_cs = V2.C; rp.v1_cs = V1.C; rp.v0_cs = V0.C;
         rp.out = out;
         rp.B = B;
+        rp.clk = nullptr;
+        // SMK_CHAIN_CLK=1 (eager runs only): print the time workgroup 0 spends in each of the nine layers
+        static const bool want_clk = getenv("SMK_CHAIN_CLK") != nullptr;
+        static unsigned long long *clk_dev = nullptr;
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        if (want_clk && hipStreamIsCapturing(s, &cst) == hipSuccess && cst == hipStreamCaptureStatusNone) {
+            if (!clk_dev) HIPCHK(hipMalloc((void **)&clk_dev, 32 * sizeof(unsigned long long)));
+            rp.clk = clk_dev;
+        }
         ProfScope ps(c, s, "refine_chain", "refine_chain", flop,
                      B * (2.0 * (7200 + 225 * 32 + 961 * 16 + 3721 * 4) + 4.0 * 16129) + wbytes);
         if (launch_refine_chain(rp, s)) return fail(SMK_E_HIP, "refine_chain launch failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rp.clk) {
+            unsigned long long hh[22];
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(hh, clk_dev, sizeof(hh), hipMemcpyDeviceToHost));
+            {
+                const unsigned long long *h = hh;
+                fprintf(stderr, "refine_chain layers (us): load=%.2f", (double)(h[1] - h[0]) * 0.01);
+                for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.2f", ids[i], (double)(h[i + 2] - h[i + 1]) * 0.01);
+                fprintf(stderr, " total=%.2f\n", (double)(h[10] - h[0]) * 0.01);
+            }
+        }
         return 0;
     }
     // stage 2 @15x15                                             (:150)
@@ -1028,6 +1054,7 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->buf) hipFree(kv.second);
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
+    if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
@@ -1307,6 +1334,13 @@ static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, con
     memset(&p, 0, sizeof(p));
     p.cls = cls; p.loc = loc; p.target_wh = target_wh; p.window = c->window_dev;
     p.pos_out = pos_out; p.box_out = box_out;
+    {   // [maxB][8] f64 | [maxB][8][8] f32 | [maxB][8] i32 | [maxB] u32
+        char *q = (char *)c->dec_scratch;
+        p.part_val = (double *)q;             q += (size_t)c->maxB * 8 * 8;
+        p.part_box = (float *)q;              q += (size_t)c->maxB * 64 * 4;
+        p.part_idx = (int *)q;                q += (size_t)c->maxB * 8 * 4;
+        p.arrived = (unsigned *)q;
+    }
     p.B = B; p.A = 5; p.S = 25; p.stride = c->anchor_stride;
     for (int i = 0; i < 5; ++i) { p.anchor_w[i] = c->anchor_w[i]; p.anchor_h[i] = c->anchor_h[i]; }
     p.penalty_k = c->penalty_k; p.window_influence = c->window_influence;

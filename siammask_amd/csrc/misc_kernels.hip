@@ -289,13 +289,18 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
 // ------------------------------------------------------------------------------------------
 // decode: softmax foreground score, anchor decode, scale/ratio penalty, cosine window, argmax.
 // Restates the host code of tools/test.py:205-254 (+ anchors of utils/anchors.py:28-51) per
-// stream, in float64 (NumPy >= 2 promotes pscore to float64 there).  One workgroup per stream,
-// 3125 candidates; ties resolve to the lowest index like np.argmax.  Removes the device->host
-// round trip between track_mask and track_refine.
+// stream, in float64 (NumPy >= 2 promotes pscore to float64 there); ties resolve to the lowest
+// index like np.argmax.  Removes the device->host round trip between track_mask and track_refine.
+//
+// The float64 exp / sqrt / divide chain of one candidate is ~800 instructions, so the 3125 candidates
+// of a stream are spread over A workgroups (one per anchor shape, one candidate per thread).  Each
+// workgroup's winner publishes its score, index and finished box; the workgroup that arrives last
+// (per-stream counter) picks among the A winners and writes the outputs -- no second launch, no
+// recomputation.  The counter is left at zero for the next launch / graph replay.
 // ------------------------------------------------------------------------------------------
-constexpr int DEC_THREADS = 1024;
+constexpr int DEC_THREADS = 640;                 // >= S*S = 625 candidates of one anchor shape
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams p) {
-    const int b = blockIdx.x, SS = p.S * p.S, n = p.A * SS;
+    const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S;
     const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
     const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
     const double tw = p.target_wh[2 * b], th = p.target_wh[2 * b + 1];
@@ -305,8 +310,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     const int ori = -(p.S / 2) * p.stride;
     double best = -1e300;
     int best_i = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int a = i / SS, rem = i - a * SS;
+    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int rem = threadIdx.x;
+    if (rem < SS) {
         const double c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
         const double score = 1.0 / (1.0 + exp(c0 - c1));          // softmax(...)[fg]
         const double aw = p.anchor_w[a], ah = p.anchor_h[a];
@@ -317,47 +323,63 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
         double s_c = sz / tsz;  s_c = fmax(s_c, 1.0 / s_c);
         double r_c = tratio / (w / h);  r_c = fmax(r_c, 1.0 / r_c);
         const double penalty = exp(-(r_c * s_c - 1.0) * p.penalty_k);
-        const double ps = penalty * score * (1.0 - p.window_influence) + p.window[rem] * p.window_influence;
-        if (ps > best || (ps == best && i < best_i)) { best = ps; best_i = i; }
+        best = penalty * score * (1.0 - p.window_influence) + p.window[rem] * p.window_influence;
+        best_i = a * SS + rem;
+        const int y = rem / p.S, x = rem - y * p.S;
+        box[0] = (float)((double)loc[(0 * p.A + a) * SS + rem] * aw + (ori + p.stride * x));
+        box[1] = (float)((double)loc[(1 * p.A + a) * SS + rem] * ah + (ori + p.stride * y));
+        box[2] = (float)w; box[3] = (float)h; box[4] = (float)score; box[5] = (float)penalty;
     }
     __shared__ double sv[DEC_THREADS];
     __shared__ int si[DEC_THREADS];
     sv[threadIdx.x] = best;
     si[threadIdx.x] = best_i;
     __syncthreads();
-    for (int s = DEC_THREADS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s && (int)threadIdx.x + s < DEC_THREADS) {
             const double v = sv[threadIdx.x + s];
             const int j = si[threadIdx.x + s];
             if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int i = si[0], a = i / SS, rem = i - a * SS, y = rem / p.S, x = rem - y * p.S;
-        if (p.pos_out) { p.pos_out[2 * b] = y; p.pos_out[2 * b + 1] = x; }
-        if (p.box_out) {
-            const double aw = p.anchor_w[a], ah = p.anchor_h[a];
-            const double c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
-            const double score = 1.0 / (1.0 + exp(c0 - c1));
-            const double cx = (double)loc[(0 * p.A + a) * SS + rem] * aw + (ori + p.stride * x);
-            const double cy = (double)loc[(1 * p.A + a) * SS + rem] * ah + (ori + p.stride * y);
-            const double w = exp((double)loc[(2 * p.A + a) * SS + rem]) * aw;
-            const double h = exp((double)loc[(3 * p.A + a) * SS + rem]) * ah;
-            const double pad = (w + h) * 0.5, sz = sqrt((w + pad) * (h + pad));
-            double s_c = sz / tsz;  s_c = fmax(s_c, 1.0 / s_c);
-            double r_c = tratio / (w / h);  r_c = fmax(r_c, 1.0 / r_c);
-            const double penalty = exp(-(r_c * s_c - 1.0) * p.penalty_k);
-            float *o = p.box_out + 8 * b;
-            o[0] = (float)cx; o[1] = (float)cy; o[2] = (float)w; o[3] = (float)h;
-            o[4] = (float)score; o[5] = (float)penalty; o[6] = (float)sv[0]; o[7] = (float)i;
-        }
+    __shared__ int s_last;
+    if (best_i == si[0]) {                           // this workgroup's winner (indices are unique)
+        float *pb = p.part_box + ((size_t)b * 8 + a) * 8;
+        for (int q = 0; q < 6; ++q) pb[q] = box[q];
+        pb[6] = (float)best;
+        pb[7] = (float)best_i;
+        p.part_val[b * 8 + a] = best;
+        p.part_idx[b * 8 + a] = best_i;
+        __threadfence();                             // publish before announcing arrival
+        const unsigned prev = __hip_atomic_fetch_add(p.arrived + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (unsigned)p.A - 1;
     }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    // last workgroup of this stream: pick among the A winners (device-coherent loads)
+    double bv = -1e300;
+    int bi = 0x7fffffff, ba = 0;
+    for (int q = 0; q < p.A; ++q) {
+        const unsigned long long raw = __hip_atomic_load((const unsigned long long *)(p.part_val + b * 8 + q), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        const double v = __longlong_as_double((long long)raw);
+        const int j = __hip_atomic_load(p.part_idx + b * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; ba = q; }
+    }
+    const int rm = bi - (bi / SS) * SS, y = rm / p.S, x = rm - y * p.S;
+    if (p.pos_out) { p.pos_out[2 * b] = y; p.pos_out[2 * b + 1] = x; }
+    if (p.box_out) {
+        const float *pb = p.part_box + ((size_t)b * 8 + ba) * 8;
+        float *o = p.box_out + 8 * b;
+        for (int q = 0; q < 8; ++q) o[q] = __hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int launch_decode(const DecodeParams &p, void *stream) {
-    if (p.A > 8 || p.B < 1) return -1;
-    hipLaunchKernelGGL(decode_kernel, dim3(p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, p);
+    if (p.A > 8 || p.B < 1 || p.S * p.S > DEC_THREADS || !p.part_val || !p.part_idx || !p.part_box || !p.arrived) return -1;
+    hipLaunchKernelGGL(decode_kernel, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -40,6 +40,14 @@ constexpr int RC_WSTAGE = RC_WROWS * RC_WPITCH * 2 + RC_WROWS * 4;     // ... + 
 constexpr int RC_TAB = 132;                          // upsampling index tables: rows, columns (ints)
 constexpr int RC_LDS = 3 * RC_BUF + 2 * RC_WSTAGE + 2 * RC_TAB * 4;    // three images + double-buffered weights + tables
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the global fetches this kernel deliberately keeps in flight across layers (measured: ~2.5 us per layer).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int CIN, int COUT>
 struct WGeo {
     static constexpr int K = 9 * CIN, KSTEPS = (K + 31) / 32, KP = KSTEPS * 32 + 8, NT = (COUT + 15) / 16;
@@ -80,6 +88,9 @@ __device__ __forceinline__ void w_store(_Float16 *wl, const WRegs<CIN, COUT> &r)
     }
     if (threadIdx.x < RC_WROWS) ((float *)(wl + RC_WROWS * RC_WPITCH))[threadIdx.x] = r.bias;
 }
+
+template <int C, int O>
+using WR = WRegs<(C ? C : 4), (C ? O : 1)>;          // C == 0: "no layer" placeholder
 
 // V_x = ReLU(v_x.2(...)) [VH*VH pixels][max(VC,8) channels] global -> registers -> the bordered LDS image that
 // h_x.2 accumulates into
@@ -139,11 +150,16 @@ __device__ __forceinline__ void zero_image(_Float16 *img) {
 //   H           output height = width;  SRC > 0: the input image is SRC x SRC and is read through
 //               nearest upsampling to H x H, SRC == 0: the input image is H x H
 //   RES         `out` already holds the other branch (V_x): add to it after the ReLU
-//   NCIN/NCOUT  next layer's weights: fetched to registers before this layer's arithmetic, staged after it
-//   VH/VC       V_x for the layer after this one: fetched likewise into the image `vimg`
-template <int CIN, int COUT, int H, int SRC, bool RELU, bool RES, bool OUT_GLOBAL, int NCIN, int NCOUT, int VH, int VC>
+//   NCIN/NCOUT  next layer's weights: already in flight to the registers `wnext`, staged into LDS after this
+//               layer's arithmetic
+//   FCIN/FCOUT  the layer after that: its fetch to `wfar` starts before this layer's arithmetic (a layer can
+//               be shorter than one global-memory round trip, two never are)
+//   VH/VC       V_x for the layer after this one: global -> registers -> the image `vimg` likewise
+template <int CIN, int COUT, int H, int SRC, bool RELU, bool RES, bool OUT_GLOBAL, int NCIN, int NCOUT, int FCIN,
+          int FCOUT, int VH, int VC>
 __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, const _Float16 *wl, _Float16 *wl_next,
-                                            const RefineChainLayer &Lnext, const _Float16 *vsrc, _Float16 *vimg,
+                                            const WR<NCIN, NCOUT> &wnext, const RefineChainLayer &Lfar,
+                                            WR<FCIN, FCOUT> &wfar, const _Float16 *vsrc, _Float16 *vimg,
                                             const int *tab, float *gout) {
     typedef WGeo<CIN, COUT> WG;
     constexpr int KSTEPS = WG::KSTEPS, KP = WG::KP, NT = WG::NT, M = H * H, MT = (M + 15) / 16;
@@ -153,24 +169,35 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- prologue: clear the output image (its border is the next layer's zero padding); start the fetches
-    WRegs<NCIN ? NCIN : 4, NCIN ? NCOUT : 1> wn;
     VRegs<VH ? VH : 1, VH ? VC : 8> vn;
-    if (NCIN) w_load<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(Lnext, wn);
+    if (FCIN) w_load<FCIN ? FCIN : 4, FCIN ? FCOUT : 1>(Lfar, wfar);
     if (VH) v_load<VH ? VH : 1, VH ? VC : 8>(vsrc, vn);
     if (!OUT_GLOBAL && !RES) zero_image<H, COUT>(out);
     if (VH) zero_image<VH ? VH : 1, VH ? VC : 8>(vimg);
     if (SRC > 0) build_up_tables<H, (SRC > 0 ? SRC : 1), CIN>((int *)tab);
-    __syncthreads();
+    lds_barrier();
 
     // ---- per-lane constants
     const int fr = lane & 15, kq = lane >> 4;
     float bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = ((const float *)(wl + RC_WROWS * RC_WPITCH))[nt * 16 + fr];
-    // K slice of this lane at step ks starts at k0 = ks*32 + kq*8: tap(s) and first channel.  In the K padding
-    // (tap > 8) the weights are zero, any finite activation will do: clamp the tap.
-    auto k_tap = [&](int ks, int add) { const int t = (ks * 32 + kq * 8 + add) / CIN; return t > 8 ? 8 : t; };
-    auto k_c0 = [&](int ks) { return (ks * 32 + kq * 8) % CIN; };
+    // K slice of this lane at step ks starts at k0 = ks*32 + kq*8: its tap (two taps when CIN = 4) and first
+    // channel, as loop-invariant offsets.  In the K padding (tap > 8) the weights are zero, any finite
+    // activation will do: clamp the tap.
+    int kh_[KSTEPS][2], kw_[KSTEPS][2], koff[KSTEPS][2];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int h = 0; h < (CIN >= 8 ? 1 : 2); ++h) {
+            const int k0 = ks * 32 + kq * 8 + h * 4;
+            int tap = k0 / CIN;
+            const int c0 = k0 - tap * CIN;
+            tap = tap > 8 ? 8 : tap;
+            kh_[ks][h] = (tap * 11) >> 5;
+            kw_[ks][h] = tap - 3 * kh_[ks][h];
+            koff[ks][h] = SRC > 0 ? c0 : (kh_[ks][h] * W2 + kw_[ks][h]) * CIN + c0;
+        }
     half8 wf[PRELOAD ? KSTEPS : 1][NT];
     if (PRELOAD) {
 #pragma unroll
@@ -183,11 +210,11 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
         int m = mt * 16 + fr;
         m = m < M ? m : M - 1;
         const int oy = m / H, ox = m - oy * H;
-        // element offset (halfs) of tap (kh, kw) of this lane's pixel in the (bordered) input image
-        auto tap_ptr = [&](int tap) {
-            const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
-            if (SRC > 0) return tab[oy + kh] + tab[RC_TAB + ox + kw];
-            return ((oy + kh) * W2 + ox + kw) * CIN;
+        // element offset (halfs) of this lane's K slice (second half-slice: h = 1) in the bordered input image
+        const int pbase = (oy * W2 + ox) * CIN;
+        auto a_off = [&](int ks, int h) {
+            if (SRC > 0) return tab[oy + kh_[ks][h]] + tab[RC_TAB + ox + kw_[ks][h]] + koff[ks][h];
+            return pbase + koff[ks][h];
         };
         floatx4 acc[NT];
 #pragma unroll
@@ -196,9 +223,9 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
         for (int ks = 0; ks < KSTEPS; ++ks) {
             half8 a;
             if (CIN >= 8) {
-                a = *(const half8 *)(in + tap_ptr(k_tap(ks, 0)) + k_c0(ks));
+                a = *(const half8 *)(in + a_off(ks, 0));
             } else {
-                const half4 lo = *(const half4 *)(in + tap_ptr(k_tap(ks, 0))), hi = *(const half4 *)(in + tap_ptr(k_tap(ks, 4)));
+                const half4 lo = *(const half4 *)(in + a_off(ks, 0)), hi = *(const half4 *)(in + a_off(ks, 1));
                 a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
@@ -235,19 +262,21 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
             }
         }
     }
-    // ---- tail: land the fetches issued in the prologue
-    if (NCIN) w_store<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(wl_next, wn);
+    // ---- tail: stage the next layer's weights (fetched a layer ago) and V_x
+    if (NCIN) w_store<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(wl_next, wnext);
     if (VH) v_store<VH ? VH : 1, VH ? VC : 8>(vimg, vn);
-    __syncthreads();
+    lds_barrier();
 }
 
 // The 4-input-channel layers (h0.0, h0.2, post2) on the vector ALU: with Cin = 4 and Cout <= 4 an MFMA pass
 // spends ~10x more instructions on im2col addressing than on arithmetic (measured: the whole chain was
 // instruction-issue bound at 102 us, post2 alone 60%), so here one lane owns one output pixel: nine 8-byte
 // LDS reads (constant offsets from one base address), 18*COUT v_dot2_f32_f16 against weights held in VGPRs.
-template <int COUT, int H, int SRC, bool RELU, bool RES, bool OUT_GLOBAL, int NCIN, int NCOUT, int VH, int VC>
+template <int COUT, int H, int SRC, bool RELU, bool RES, bool OUT_GLOBAL, int NCIN, int NCOUT, int FCIN, int FCOUT,
+          int VH, int VC>
 __device__ __forceinline__ void chain_layer_c4(const _Float16 *in, _Float16 *out, const _Float16 *wl, _Float16 *wl_next,
-                                               const RefineChainLayer &Lnext, const _Float16 *vsrc, _Float16 *vimg,
+                                               const WR<NCIN, NCOUT> &wnext, const RefineChainLayer &Lfar,
+                                               WR<FCIN, FCOUT> &wfar, const _Float16 *vsrc, _Float16 *vimg,
                                                const int *tab, float *gout) {
     typedef WGeo<4, COUT> WG;
     constexpr int KP = WG::KP, M = H * H;
@@ -255,14 +284,13 @@ __device__ __forceinline__ void chain_layer_c4(const _Float16 *in, _Float16 *out
     static_assert(COUT == 4 || COUT == 1, "output channels");
     const int tid = threadIdx.x;
 
-    WRegs<NCIN ? NCIN : 4, NCIN ? NCOUT : 1> wn;
     VRegs<VH ? VH : 1, VH ? VC : 8> vn;
-    if (NCIN) w_load<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(Lnext, wn);
+    if (FCIN) w_load<FCIN ? FCIN : 4, FCIN ? FCOUT : 1>(Lfar, wfar);
     if (VH) v_load<VH ? VH : 1, VH ? VC : 8>(vsrc, vn);
     if (!OUT_GLOBAL && !RES) zero_image<H, COUT>(out);
     if (VH) zero_image<VH ? VH : 1, VH ? VC : 8>(vimg);
     if (SRC > 0) build_up_tables<H, (SRC > 0 ? SRC : 1), 4>((int *)tab);
-    __syncthreads();
+    lds_barrier();
 
     half2v wv[COUT][9][2];                                     // [out channel][tap][channel pair]
     float bias[COUT];
@@ -332,13 +360,15 @@ __device__ __forceinline__ void chain_layer_c4(const _Float16 *in, _Float16 *out
             }
         }
     }
-    if (NCIN) w_store<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(wl_next, wn);
+    if (NCIN) w_store<NCIN ? NCIN : 4, NCIN ? NCOUT : 1>(wl_next, wnext);
     if (VH) v_store<VH ? VH : 1, VH ? VC : 8>(vimg, vn);
-    __syncthreads();
+    lds_barrier();
 }
 
 }  // namespace
 
+// TIMED: workgroup 0 also records a timestamp per layer (SMK_CHAIN_CLK=1; see engine.cpp)
+template <bool TIMED>
 __global__ __launch_bounds__(1024) void refine_chain_kernel(const RefineChainParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[RC_LDS];
     _Float16 *bA = (_Float16 *)smem, *bB = (_Float16 *)(smem + RC_BUF), *bC = (_Float16 *)(smem + 2 * RC_BUF);
@@ -348,34 +378,55 @@ __global__ __launch_bounds__(1024) void refine_chain_kernel(const RefineChainPar
     const _Float16 *v1 = (const _Float16 *)p.v1 + (size_t)b * (961 * 16);
     const _Float16 *v0 = (const _Float16 *)p.v0 + (size_t)b * (3721 * 8);
     float *gout = p.out + (size_t)b * (127 * 127);
+    int *tab = (int *)(smem + 3 * RC_BUF + 2 * RC_WSTAGE);
+    unsigned long long *clk = TIMED && p.clk && blockIdx.x == 0 && threadIdx.x == 0 ? p.clk : nullptr;
+    if (TIMED && clk) clk[0] = wall_clock64();
+    // weights of layer i+1 / i+2 in flight (registers) while layer i computes
+    WRegs<32, 32> r1;
+    WRegs<32, 16> r2;
+    WRegs<16, 16> r3, r4;
+    WRegs<16, 4> r5;
+    WRegs<4, 4> r6, r7;
+    WRegs<4, 1> r8, none;
     // deconv output [15*15][32] -> bordered image A; first layer's weights
     {
-        WRegs<32, 32> wr;
+        WRegs<32, 32> r0;
         VRegs<15, 32> dr;
-        w_load<32, 32>(p.L[0], wr);
+        w_load<32, 32>(p.L[0], r0);
         v_load<15, 32>((const _Float16 *)p.d + (size_t)b * 7200, dr);
+        w_load<32, 32>(p.L[1], r1);
         zero_image<15, 32>(bA);
-        __syncthreads();
-        w_store<32, 32>(w0, wr);
+        lds_barrier();
+        w_store<32, 32>(w0, r0);
         v_store<15, 32>(bA, dr);
         // chain_layer's prologue barrier orders these writes before the first reads
     }
-    int *tab = (int *)(smem + 3 * RC_BUF + 2 * RC_WSTAGE);
-    //          CIN COUT  H  SRC  RELU   RES  GLOBAL  next W   next V
-    chain_layer<32, 32, 15, 0, true, false, false, 32, 32, 15, 32>(bA, bB, w0, w1, p.L[1], v2, bC, tab, nullptr);       // h2.0
-    chain_layer<32, 32, 15, 0, true, true, false, 32, 16, 0, 0>(bB, bC, w1, w0, p.L[2], nullptr, nullptr, tab, nullptr);    // h2.2 + V2
-    chain_layer<32, 16, 31, 15, false, false, false, 16, 16, 0, 0>(bC, bA, w0, w1, p.L[3], nullptr, nullptr, tab, nullptr); // post0(up31)
-    chain_layer<16, 16, 31, 0, true, false, false, 16, 16, 31, 16>(bA, bB, w1, w0, p.L[4], v1, bC, tab, nullptr);       // h1.0
-    chain_layer<16, 16, 31, 0, true, true, false, 16, 4, 0, 0>(bB, bC, w0, w1, p.L[5], nullptr, nullptr, tab, nullptr);     // h1.2 + V1
-    chain_layer<16, 4, 61, 31, false, false, false, 4, 4, 0, 0>(bC, bA, w1, w0, p.L[6], nullptr, nullptr, tab, nullptr);    // post1(up61)
-    chain_layer_c4<4, 61, 0, true, false, false, 4, 4, 61, 4>(bA, bB, w0, w1, p.L[7], v0, bC, tab, nullptr);            // h0.0
-    chain_layer_c4<4, 61, 0, true, true, false, 4, 1, 0, 0>(bB, bC, w1, w0, p.L[8], nullptr, nullptr, tab, nullptr);        // h0.2 + V0
-    chain_layer_c4<1, 127, 61, false, false, true, 0, 0, 0, 0>(bC, nullptr, w0, nullptr, p.L[8], nullptr, nullptr, tab, gout);  // post2(up127)
+    if (TIMED && clk) clk[1] = wall_clock64();
+    //          CIN COUT  H  SRC  RELU   RES  GLOBAL  next W  W after  next V
+    chain_layer<32, 32, 15, 0, true, false, false, 32, 32, 32, 16, 15, 32>(bA, bB, w0, w1, r1, p.L[2], r2, v2, bC, tab, nullptr);  // h2.0
+    if (TIMED && clk) clk[2] = wall_clock64();
+    chain_layer<32, 32, 15, 0, true, true, false, 32, 16, 16, 16, 0, 0>(bB, bC, w1, w0, r2, p.L[3], r3, nullptr, nullptr, tab, nullptr);  // h2.2 + V2
+    if (TIMED && clk) clk[3] = wall_clock64();
+    chain_layer<32, 16, 31, 15, false, false, false, 16, 16, 16, 16, 0, 0>(bC, bA, w0, w1, r3, p.L[4], r4, nullptr, nullptr, tab, nullptr);  // post0(up31)
+    if (TIMED && clk) clk[4] = wall_clock64();
+    chain_layer<16, 16, 31, 0, true, false, false, 16, 16, 16, 4, 31, 16>(bA, bB, w1, w0, r4, p.L[5], r5, v1, bC, tab, nullptr);  // h1.0
+    if (TIMED && clk) clk[5] = wall_clock64();
+    chain_layer<16, 16, 31, 0, true, true, false, 16, 4, 4, 4, 0, 0>(bB, bC, w0, w1, r5, p.L[6], r6, nullptr, nullptr, tab, nullptr);  // h1.2 + V1
+    if (TIMED && clk) clk[6] = wall_clock64();
+    chain_layer<16, 4, 61, 31, false, false, false, 4, 4, 4, 4, 0, 0>(bC, bA, w1, w0, r6, p.L[7], r7, nullptr, nullptr, tab, nullptr);  // post1(up61)
+    if (TIMED && clk) clk[7] = wall_clock64();
+    chain_layer_c4<4, 61, 0, true, false, false, 4, 4, 4, 1, 61, 4>(bA, bB, w0, w1, r7, p.L[8], r8, v0, bC, tab, nullptr);  // h0.0
+    if (TIMED && clk) clk[8] = wall_clock64();
+    chain_layer_c4<4, 61, 0, true, true, false, 4, 1, 0, 0, 0, 0>(bB, bC, w1, w0, r8, p.L[8], none, nullptr, nullptr, tab, nullptr);  // h0.2 + V0
+    if (TIMED && clk) clk[9] = wall_clock64();
+    chain_layer_c4<1, 127, 61, false, false, true, 0, 0, 0, 0, 0, 0>(bC, nullptr, w0, nullptr, none, p.L[8], none, nullptr, nullptr, tab, gout);  // post2
+    if (TIMED && clk) clk[10] = wall_clock64();
 }
 
 int launch_refine_chain(const RefineChainParams &p, void *stream) {
     if (p.v2_cs != 32 || p.v1_cs != 16 || p.v0_cs != 8) return -1;      // the layouts v_load assumes
-    hipLaunchKernelGGL(refine_chain_kernel, dim3(p.B), dim3(RC_NT), 0, (hipStream_t)stream, p);
+    if (p.clk) hipLaunchKernelGGL(refine_chain_kernel<true>, dim3(p.B), dim3(RC_NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(refine_chain_kernel<false>, dim3(p.B), dim3(RC_NT), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -160,6 +160,11 @@ struct DecodeParams {
     const double *window;    // [S*S] cosine window (outer(hanning, hanning))
     int *pos_out;            // [B][2] (y, x) of the best anchor position
     float *box_out;          // [B][8] cx, cy, w, h (crop pixels), score, penalty, pscore, best_id
+    // scratch for the cross-workgroup argmax: winners per (stream, anchor shape); `arrived` starts at 0
+    double *part_val;        // [B][8]
+    int *part_idx;           // [B][8]
+    float *part_box;         // [B][8][8]
+    unsigned *arrived;       // [B]
     int B, A, S, stride;
     float anchor_w[8], anchor_h[8];
     double penalty_k, window_influence;
@@ -206,6 +211,7 @@ struct RefineChainParams {
     RefineChainLayer L[9];                // h2.0 h2.2 post0 h1.0 h1.2 post1 h0.0 h0.2 post2
     float *out;                           // [B][127*127] f32
     int B;
+    unsigned long long *clk;              // optional [11]: 100 MHz timestamps of workgroup 0 at the layer boundaries
 };
 int launch_refine_chain(const RefineChainParams &p, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
