@@ -145,7 +145,12 @@ int smk_set_graph_mode(smk_ctx *ctx, int enable);
  *   "buf_lds" 0|1 (LDS-DMA through buffer resources; default 1)   "xc_ch" 64|32 (dw-xcorr channels per workgroup; null)
  *   "prio" -1..3 (s_setprio of the consumer waves; measured null)   "mask_overlap" 0|1 (mask head on a graph side
  *   branch; measured slower)   "concurrency" 0|1 (fork/join between independent launches; measured slower; applies to
- *   contexts created afterwards). */
+ *   contexts created afterwards)
+ *   "halo" 0|1|64|128 (3x3 stride-1 convolutions through conv3x3_halo_kernel: off | per-shape choice (default, fp16) |
+ *   force that workgroup height)   "chain" 0|1 (fp16: Refine's nine sequential convolutions as one launch,
+ *   refine_chain_kernel; default 1).
+ * Environment: SMK_CHAIN_CLK=1 makes eager (non-graph) runs print the time workgroup 0 spends in each layer of
+ * refine_chain_kernel to stderr (measurement aid). */
 int smk_tune(const char *key, int value);
 
 /* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the
