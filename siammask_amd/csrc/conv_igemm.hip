@@ -191,6 +191,15 @@ void conv_igemm_kernel(const ConvBatch cb) {
         const int x = t & 7, j = t >> 3;
         t = x * q + (x < r ? x : r) + j;
     }
+    // split-K (p.ksplit > 1, NHWC epilogue only): `ksplit` consecutive workgroups share an output tile, each
+    // runs 1/ksplit of the K loop; the one that finishes last adds the partial tiles up (see the epilogue).
+    // Consecutive t -> same XCD under xcd_mode 1, so the partial tiles meet in one L2.
+    const int ksplit = (OUT_MODE == OUT_NHWC && p.ksplit > 1) ? p.ksplit : 1;
+    int ks = 0;
+    if (ksplit > 1) {
+        ks = t % ksplit;
+        t = t / ksplit;
+    }
     int tm, tn;
     if (p.xcd_mode == 2) {            // tn-major: each XCD owns a range of weight panels
         const int tilesM = (p.M + BM - 1) / BM;
@@ -199,7 +208,8 @@ void conv_igemm_kernel(const ConvBatch cb) {
         tm = t / tilesN; tn = t - tm * tilesN;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = ((p.K + BK - 1) / BK) / ksplit;     // K tiles of THIS workgroup (the host makes it divide)
+    const int kt0 = ks * nk;                           // its first K tile
 
     floatx16 acc[2][2];                // consumers only
 
@@ -310,8 +320,8 @@ void conv_igemm_kernel(const ConvBatch cb) {
 #pragma unroll
         for (int tt = 0; tt < AHEAD; ++tt)
             if (tt < nk) {
-                set_tile(tt);
-                issue_tile(tt, tt);
+                set_tile(kt0 + tt);
+                issue_tile(kt0 + tt, tt);
             }
         int islot = AHEAD;                                 // slot of tile kt + AHEAD
         if (islot == NSTAGE) islot = 0;
@@ -323,8 +333,8 @@ void conv_igemm_kernel(const ConvBatch cb) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + AHEAD < nk) {
-                set_tile(kt + AHEAD);
-                issue_tile(kt + AHEAD, islot);
+                set_tile(kt0 + kt + AHEAD);
+                issue_tile(kt0 + kt + AHEAD, islot);
             }
             if (++islot == NSTAGE) islot = 0;
         }
@@ -456,7 +466,76 @@ void conv_igemm_kernel(const ConvBatch cb) {
     // region of consumer (wm, wn, wk): ((wm*WN + wn)*WK + wk) * 64*LDE floats
     if (OUT_MODE == OUT_NHWC) {
         const int n = n0 + c4;
-        if (n < p.Nst) {
+        const bool ncol_ok = n < p.Nst;
+        // K-group sums of this thread's NPASS x EV outputs
+        float vv[NPASS][EV];
+        {
+            const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int row = ps * RPP + r0;
+                const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
+#pragma unroll
+                for (int q = 0; q < EV; q += 4) {
+                    floatx4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (row < BM) {
+                        x = *(const floatx4 *)(er + q);
+#pragma unroll
+                        for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (64 * LDE) + q);
+                    }
+                    vv[ps][q] = x[0]; vv[ps][q + 1] = x[1]; vv[ps][q + 2] = x[2]; vv[ps][q + 3] = x[3];
+                }
+            }
+        }
+        if (ksplit > 1) {
+            // partial tiles in thread-linear order [tile][ks][pass][thread][EV] f32: every thread later reads
+            // back exactly the addresses its counterparts wrote (coalesced both ways).  The workgroup that
+            // arrives last at the tile's counter sums ALL partials in the fixed order ks = 0..ksplit-1
+            // (its own included), so the result does not depend on the arrival order.
+            const size_t tile_id = (size_t)tm * tilesN + tn;
+            // No fences: an agent-scope release / acquire would write back and invalidate the whole L2 of the
+            // XCD per workgroup (measured: +35 % on the B=8 step).  The partial tiles travel with sc1 (device
+            // coherent: write-through / L2-bypassing) buffer accesses instead, `s_waitcnt vmcnt(0)` makes the
+            // stores complete before the arrival counter is bumped, and the counter is a device-scope atomic.
+            constexpr int PART = NPASS * NT * EV;                        // f32 per (tile, part)
+            typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(p.ks_part + tile_id * ksplit * PART), 0, (int)(ksplit * PART * sizeof(float)), 0x00020000);
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+                for (int q = 0; q < EV; q += 4) {
+                    const uint4v d = {__float_as_uint(vv[ps][q]), __float_as_uint(vv[ps][q + 1]),
+                                      __float_as_uint(vv[ps][q + 2]), __float_as_uint(vv[ps][q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs_part, (int)((((ks * NPASS + ps) * NT + tid) * EV + q) * sizeof(float)), 0, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of the partial tile is in memory
+            __syncthreads();                                   // ... and everybody's; LDS is free from here on
+            int *flag = (int *)smem;
+            if (tid == 0) {
+                const unsigned prev = __hip_atomic_fetch_add(p.ks_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = prev == (unsigned)ksplit - 1;
+            }
+            __syncthreads();
+            if (!*flag) return;
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+                for (int q = 0; q < EV; ++q) vv[ps][q] = 0.f;
+            for (int s2 = 0; s2 < ksplit; ++s2) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+                    for (int q = 0; q < EV; q += 4) {
+                        const uint4v x = __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_part, (int)((((s2 * NPASS + ps) * NT + tid) * EV + q) * sizeof(float)), 0, 16);
+                        vv[ps][q] += __uint_as_float(x[0]); vv[ps][q + 1] += __uint_as_float(x[1]);
+                        vv[ps][q + 2] += __uint_as_float(x[2]); vv[ps][q + 3] += __uint_as_float(x[3]);
+                    }
+            }
+            if (tid == 0) __hip_atomic_store(p.ks_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+        }
+        if (ncol_ok) {
             float bv[EV];
 #pragma unroll
             for (int q = 0; q < EV; q += 4) {
@@ -464,24 +543,15 @@ void conv_igemm_kernel(const ConvBatch cb) {
                 bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
             }
             T *out = (T *)p.out;
-            const float *ecol = ebase + ((c4 >> 6) * WK) * (64 * LDE) + (c4 & 63);
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + r0;
                 const int m = m0 + row;
                 if (row < BM && m < p.M) {
-                    const float *er = ecol + ((row >> 6) * WN * WK) * (64 * LDE) + (row & 63) * LDE;
                     float v[EV];
 #pragma unroll
-                    for (int q = 0; q < EV; q += 4) {
-                        floatx4 x = *(const floatx4 *)(er + q);
-#pragma unroll
-                        for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (64 * LDE) + q);
-                        v[q] = x[0]; v[q + 1] = x[1]; v[q + 2] = x[2]; v[q + 3] = x[3];
-                    }
-#pragma unroll
                     for (int q = 0; q < EV; ++q) {
-                        float x = v[q] + bv[q];
+                        float x = vv[ps][q] + bv[q];
                         if (p.res_mode == RES_PRE_RELU) x += rv[ps][q];
                         if (p.relu) x = fmaxf(x, 0.f);
                         if (p.res_mode == RES_POST_RELU) x += rv[ps][q];
@@ -949,15 +1019,56 @@ TileChoice choose_tile(const ConvParams &p, int dtype) {
     return t;
 }
 
+// Split-K policy.  The emulation without the reduction (profiles/r01_v6_splitk_probe.txt) promised 2-6 us per
+// under-filled launch.  Measured with the real exchange (sc1 stores -> counter -> sc1 loads: three dependent trips
+// to device-coherent memory; profiles/r01_v6_ksplit_launch.txt, r01_v6_ksplit_ab.txt):
+//   * alone on the chip it pays only for long K on few tiles: Refine's v2.0 (K=4608) 21 -> 14 us (x4) at B=8,
+//     21 -> 12 us at B=1; layer3 conv2 at B=1 15 -> 13 us; everything shorter loses;
+//   * beside other work the exchange is slow: layer3 conv1 at B=8 10.6 -> 25 (x2) / 42 us (x4), and v2.0 inside
+//     its merged launch (830 workgroups, chip full) made the B=8 step 0.915 -> 0.955 ms.
+// Hence off by default (g_tune.ksplit = 0; B=1 step 0.537 -> 0.531 ms with auto); auto mode only takes
+// K >= 4096 with at most one workgroup per CU after the split and evenly dividing K tiles.
+static int pick_ksplit(const ConvParams &p, int bm, int tiles, int nk) {
+    const int mode = g_tune.ksplit;                // 0 off, 1 auto, 2 / 4 forced (tests)
+    if (!mode || p.groups > 1 || bm > 128) return 1;
+    if (mode == 1 && p.K < 4096) return 1;
+    for (int sp = 4; sp >= 2; sp >>= 1) {
+        if (mode != 1 && sp != mode) continue;
+        if (nk % sp == 0 && nk / sp >= (mode == 1 ? 4 : 1) && (mode != 1 || tiles * sp <= 256)) return sp;
+    }
+    return 1;
+}
+
+int conv_ksplit(const ConvParams &p, int dtype, const TileChoice &t) {
+    if (p.out_mode != OUT_NHWC || !p.ks_part) return 1;
+    const int bk = t.kt / (dtype == DT_F16 ? 2 : 4);
+    return pick_ksplit(p, t.bm, ((p.M + t.bm - 1) / t.bm) * ((p.Nst + t.bn - 1) / t.bn), (p.K + bk - 1) / bk);
+}
+
 template <typename T, int WM, int WN, int WK, int KT, int OM>
 static int launch_stages(ConvBatch &cb, int stages, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NTHREADS = (WM * WN * WK + 4) * 64;
+    constexpr int BK_ = KT / (int)sizeof(T);
     int total = 0, groups = 1;
+    size_t part_used = 0;                 // floats / counters of the split-K scratch handed out so far
+    int cnt_used = 0;
+    constexpr int EVh = Traits<T>::EV, LPRh = BN / EVh, RPPh = NTHREADS / LPRh, NPASSh = (BM + RPPh - 1) / RPPh;
+    constexpr size_t PART_PER_SPLIT = (size_t)NPASSh * NTHREADS * EVh;     // f32 per (tile, split)
     for (int i = 0; i < cb.n; ++i) {
-        const ConvParams &p = cb.p[i];
+        ConvParams &p = cb.p[i];
         cb.start[i] = total;
-        total += ((p.M + BM - 1) / BM) * ((p.Nst + BN - 1) / BN);
+        const int tiles = ((p.M + BM - 1) / BM) * ((p.Nst + BN - 1) / BN);
+        int sp = (OM == OUT_NHWC && p.ks_part) ? pick_ksplit(p, BM, tiles, (p.K + BK_ - 1) / BK_) : 1;
+        if (sp > 1 && (part_used + (size_t)tiles * sp * PART_PER_SPLIT > p.ks_part_cap || cnt_used + tiles > p.ks_cnt_cap)) sp = 1;
+        p.ksplit = sp;
+        if (sp > 1) {
+            p.ks_part += part_used;
+            p.ks_cnt += cnt_used;
+            part_used += (size_t)tiles * sp * PART_PER_SPLIT;
+            cnt_used += tiles;
+        }
+        total += tiles * sp;
         if (p.groups > groups) groups = p.groups;
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;

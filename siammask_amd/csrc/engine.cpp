@@ -103,6 +103,8 @@ struct PackedConv {
     int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
 };
 
+constexpr size_t KS_PART_FLOATS = 8u << 20;      // 32 MB: e.g. 256 tiles x 4 parts x 64x128
+constexpr int KS_CNT = 8192;
 constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 4 + 8 * 4 + 4;     // decode_kernel's cross-workgroup scratch
 
 static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
@@ -186,6 +188,8 @@ struct smk_ctx {
     std::map<std::string, size_t> buf_elems;  // per item
     int *pos_dev = nullptr;
     void *dec_scratch = nullptr;     // decode: per-stream winners of the A workgroups + arrival counters
+    float *ks_part = nullptr;        // split-K: f32 partial tiles (KS_PART_FLOATS) and per-tile arrival counters
+    unsigned *ks_cnt = nullptr;
 
     // decode (tools/test.py:205-254 on device)
     float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
@@ -474,6 +478,9 @@ static int build_arena(smk_ctx *c) {
     }
     HIPCHK(hipMalloc((void **)&c->pos_dev, sizeof(int) * 2 * c->maxB));
     HIPCHK(hipMemset(c->pos_dev, 0, sizeof(int) * 2 * c->maxB));
+    HIPCHK(hipMalloc((void **)&c->ks_part, KS_PART_FLOATS * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->ks_cnt, KS_CNT * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->ks_cnt, 0, KS_CNT * sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->dec_scratch, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
     HIPCHK(hipMemset(c->dec_scratch, 0, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
     return 0;
@@ -581,7 +588,11 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         p.res_coff = o.res_coff;
         p.res_mode = o.res_mode;
     }
-    (void)c;
+    p.ksplit = 1;
+    p.ks_part = c->ks_part;
+    p.ks_cnt = c->ks_cnt;
+    p.ks_part_cap = c->ks_part ? KS_PART_FLOATS : 0;
+    p.ks_cnt_cap = c->ks_cnt ? KS_CNT : 0;
     return 0;
 }
 
@@ -636,7 +647,8 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
     int rc = 1;
-    const int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
+    int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
+    if (bm && !o.halo && conv_ksplit(p, c->dtype, t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
     if (bm) {
         // 3x3 stride-1: the activation patch is staged once per channel chunk and shared by the nine taps
         ConvParams ph = p;
@@ -1055,6 +1067,8 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
+    if (c->ks_part) hipFree(c->ks_part);
+    if (c->ks_cnt) hipFree(c->ks_cnt);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
@@ -1273,6 +1287,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
+    else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
@@ -1474,6 +1489,23 @@ static void pack_host(const smk_conv_geom *g, const PackedConv &pc, const float 
     if (b) for (int n = 0; n < g->Cout; ++n) bias[n] = b[n];
 }
 
+// split-K scratch of the context-free entry points (per-op tests, smk_bench_conv): one per device, lazily
+static int op_ks_scratch(smk_ctx &fake) {
+    static float *part[64] = {nullptr};
+    static unsigned *cnt[64] = {nullptr};
+    const int d = fake.device;
+    if (d < 0 || d >= 64) return 0;
+    if (!part[d]) {
+        HIPCHK(hipMalloc((void **)&part[d], KS_PART_FLOATS * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&cnt[d], KS_CNT * sizeof(unsigned)));
+        HIPCHK(hipMemset(cnt[d], 0, KS_CNT * sizeof(unsigned)));
+    }
+    fake.ks_part = part[d];
+    fake.ks_cnt = cnt[d];
+    return 0;
+}
+
+
 int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x_dev, const float *w_host,
                      const float *b_host, const float *res_dev, const int32_t *pos_host, float *y_dev,
                      void *stream) {
@@ -1520,6 +1552,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     smk_ctx fake;
     fake.dtype = dtype;
     HIPCHK(hipGetDevice(&fake.device));
+    CHK(op_ks_scratch(fake));
     ConvParams p;
     if (nchw) {
         o.nchw_out = y_dev;
@@ -1711,6 +1744,7 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
     smk_ctx fake;
     fake.dtype = dtype;
     HIPCHK(hipGetDevice(&fake.device));
+    CHK(op_ks_scratch(fake));
     ConvParams p;
     CHK(conv_params(&fake, pc, in, mode == 2 ? nullptr : &out, g->B, o, p));
     const TileChoice t = tile_from_code(o.tile_code, p, dtype);

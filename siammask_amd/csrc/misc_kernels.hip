@@ -345,14 +345,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     }
     __shared__ int s_last;
     if (best_i == si[0]) {                           // this workgroup's winner (indices are unique)
+        // device-coherent (sc1) stores + vmcnt(0) instead of a release fence: an agent-scope fence writes back
+        // and invalidates the XCD's whole L2
         float *pb = p.part_box + ((size_t)b * 8 + a) * 8;
-        for (int q = 0; q < 6; ++q) pb[q] = box[q];
-        pb[6] = (float)best;
-        pb[7] = (float)best_i;
-        p.part_val[b * 8 + a] = best;
-        p.part_idx[b * 8 + a] = best_i;
-        __threadfence();                             // publish before announcing arrival
-        const unsigned prev = __hip_atomic_fetch_add(p.arrived + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 6; ++q) __hip_atomic_store(pb + q, box[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pb + 6, (float)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pb + 7, (float)best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long *)(p.part_val + b * 8 + a), (unsigned long long)__double_as_longlong(best),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.part_idx + b * 8 + a, best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // published before announcing arrival
+        const unsigned prev = __hip_atomic_fetch_add(p.arrived + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == (unsigned)p.A - 1;
     }
     __syncthreads();

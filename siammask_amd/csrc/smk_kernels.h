@@ -58,6 +58,13 @@ struct ConvParams {
     int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
     unsigned in_bytes, w_bytes;   // extents of the input tensor / weight pack for the SRDs
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
+    // split-K across workgroups (NHWC epilogue): scratch for the f32 partial tiles and one arrival counter per
+    // tile (zero between launches); ksplit is decided at launch (launch_conv_mfma_batch), 1 = off
+    int ksplit;
+    float *ks_part;
+    unsigned *ks_cnt;
+    size_t ks_part_cap;    // floats
+    int ks_cnt_cap;
 };
 
 // several independent convolutions in one launch (same kernel instantiation for all of them)
@@ -80,6 +87,8 @@ struct Tuning {
     int halo = 1;              // 3x3 stride-1 convolutions through conv3x3_halo_kernel (0 off, 1 per-shape choice,
                                // 128 / 64 force that workgroup height)
     int chain = 1;             // fp16: Refine's sequential tail as one launch (refine_chain_kernel)
+    int ksplit = 0;            // split-K across workgroups: 0 off (default: measured a net loss at B=8, +1 % at B=1,
+                               // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
     int xc_ch = 64;            // dw_xcorr: channels per workgroup (64 or 32)
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
@@ -195,6 +204,8 @@ TileChoice choose_tile(const ConvParams &p, int dtype);
 int launch_conv_mfma(const ConvParams &p, int dtype, TileChoice t, void *stream);
 int launch_conv_mfma_batch(ConvBatch &cb, int dtype, TileChoice t, void *stream);
 int launch_conv_naive(const ConvParams &p, int dtype, void *stream);
+// the split-K factor launch_conv_mfma_batch would use for this problem with this tile (1 = none)
+int conv_ksplit(const ConvParams &p, int dtype, const TileChoice &t);
 // 3x3 stride-1 convolution with the activation patch shared by the nine taps (chunk-major weight pack);
 // returns 1 when the geometry is not eligible
 int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);

@@ -115,6 +115,42 @@ def test_conv3x3_halo_windows():
         assert rel_err(y.cpu().numpy(), ref) <= TOL[dtype]
 
 
+SPLITK_CASES = [
+    # cin, cout, k, pad, hw, B     K tiles (f16, 128-byte tile): 36 / 4 / 72 / 16
+    (256, 96, 3, 1, 15, 2),
+    (256, 64, 1, 0, 13, 1),
+    (512, 128, 3, 1, 9, 1),
+    (1024, 256, 1, 0, 15, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("cfg", SPLITK_CASES)
+def test_conv_split_k(cfg, dtype):
+    """split-K across workgroups (partial tiles in scratch, last-arrival reduction, counters self-resetting):
+    forced 2- and 4-way splits on every tile shape that allows them, against the oracle; bias + ReLU + residual.
+    The second call of each configuration re-uses the counters the first one left behind."""
+    from siammask_amd import _lib
+    ops = _ops()
+    cin, cout, k, pad, hw, B = cfg
+    rng = np.random.default_rng(hash(cfg) & 0xffff)
+    x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k), _rand(rng, cout)
+    ho = hw + 2 * pad - (k - 1)
+    res = _rand(rng, B, cout, ho, ho)
+    ref = np.maximum(O.conv2d(_q(x, dtype), _q(w, dtype), b.astype(np.float64), 1, pad, 1) + _q(res, dtype), 0)
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
+    try:
+        for sp in (2, 4):
+            _lib.tune(ksplit=sp)
+            for tile in ((64, 64), (64, 128), (128, 64), (128, 128)):
+                for rep in range(2):
+                    y = ops.conv2d(xd, w, b, 1, pad, 1, relu=True, res=rd, res_mode=1, dtype=dtype, tile=tile)
+                    e = rel_err(y.cpu().numpy(), ref)
+                    assert e <= TOL[dtype], "split-K x%d %s %s tile %s rep %d: %.3e" % (sp, cfg, dtype, tile, rep, e)
+    finally:
+        _lib.tune(ksplit=1)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_conv_epilogues(dtype):
     """bias + residual (before / after ReLU) + ReLU, as used by Bottleneck (resnet.py:99-101)
