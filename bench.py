@@ -198,7 +198,7 @@ def roofline(w, steps=3):
                             "tflops": round(heavy["flop"] / (heavy["ms"] * 1e-3) / 1e12, 2)},
         "kernel_ms_per_step": round(total_ms / steps, 4),
     }
-    # HBM bytes per launch from the PMC counters (collected offline by tests/gpu_pmc.sh with rocprofv3
+    # HBM bytes per launch from the PMC counters (collected offline by tools/measure/gpu_pmc.sh with rocprofv3
     # --pmc in separate passes and committed under profiles/; cannot be sampled from inside this process)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % w.name)
     if os.path.exists(pmc):

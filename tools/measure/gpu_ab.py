@@ -2,7 +2,7 @@
 """Generic in-process A/B of one smk_tune knob on the heavy conv shapes + the end-to-end step.
 usage: gpu_ab.py <knob> <v0,v1,...>"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import _lib, ops, synth
 from siammask_amd.custom import build

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """What does the residual cost the short-K wide-N 1x1 convolutions (bottleneck conv3)?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import ops
 SH = {"l1.c3": (64, 63, 256), "l2.c3": (128, 31, 512), "l3.c3": (256, 31, 1024)}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """per-launch times of the Refine part (eager, HIP events) with the chain kernel on / off"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import _lib, synth
 from siammask_amd.custom import build

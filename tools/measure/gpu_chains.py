@@ -2,7 +2,7 @@
 """Experiment: B streams as N independent chains (N contexts x B/N streams) on N HIP streams,
 vs one chain of B.  Measures whether concurrent chains fill the launch/tail bubbles."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from siammask_amd import synth

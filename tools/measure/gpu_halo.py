@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """conv3x3_halo_kernel against the generic implicit-GEMM kernel: per-shape launch time, then the whole step."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import _lib, ops, synth
 from siammask_amd.custom import build

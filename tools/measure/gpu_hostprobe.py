@@ -1,6 +1,6 @@
 """Where does host time go per step?  (graph vs eager; per-call enqueue cost)"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from bench import Workload
 from siammask_amd import _lib

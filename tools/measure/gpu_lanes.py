@@ -2,7 +2,7 @@
 """Does splitting a batch of streams into L independent lanes (own context, own HIP stream, own graph)
 overlap the latency-bound launches?  total batch fixed; per-step join vs free-running."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import synth
 from siammask_amd.custom import build

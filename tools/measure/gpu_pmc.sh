@@ -12,6 +12,6 @@ for SET in "$@"; do
   echo "pass $i [$SET] exit $?"
 done
 cd $R
-python tests/pmc_stats.py gpurun_out/pmc
+python tools/measure/pmc_stats.py gpurun_out/pmc
 # drop raw traces that are too large to bring back
 find gpurun_out/pmc -name "*.csv" -size +12M -delete

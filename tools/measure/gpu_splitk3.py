@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """real split-K (with the reduction) per launch on the shapes the probe looked at"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import _lib, ops
 SH = {"v2.0": (512, 15, 128, 3, 1, 1, 1), "l3.c2": (256, 31, 256, 3, 1, 2, 2), "l3.c1": (1024, 31, 256, 1, 1, 0, 1),

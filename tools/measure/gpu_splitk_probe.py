@@ -2,7 +2,7 @@
 """Would splitting K across workgroups help the under-filled launches?  Emulation without the reduction:
 time(B*s streams, Cin/s channels) has the same MACs, s x the workgroups and 1/s of the K loop."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa
 from siammask_amd import ops
 SH = {"l3.c2": (256, 31, 256, 3, 1, 2, 2), "l3.c1": (1024, 31, 256, 1, 1, 0, 1), "l3.c3": (256, 31, 1024, 1, 1, 0, 1),

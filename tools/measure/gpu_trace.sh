@@ -6,5 +6,5 @@ cat gpurun_out/bench.json | head -c 1500; echo
 cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also --tune "${TUNE:-stages=0}" > $R/gpurun_out/rocprof_bench.json 2> $R/gpurun_out/rocprof.err
 cd $R
-python tests/trace_stats.py
+python tools/measure/trace_stats.py
 find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete

@@ -10,4 +10,4 @@ timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof -- pyt
 echo "rocprof exit $?"
 find $R/gpurun_out/prof -name "*kernel_trace.csv" -delete
 cd $R
-[ -n "$NO_PMC" ] || bash tests/gpu_pmc.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" 2>&1 | tail -40
+[ -n "$NO_PMC" ] || bash tools/measure/gpu_pmc.sh "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum" 2>&1 | tail -40

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic_<workload>.json from the per-kernel PMC sums (tests/pmc_stats.py output):
+"""profiles/pmc_traffic_<workload>.json from the per-kernel PMC sums (tools/measure/pmc_stats.py output):
 HBM bytes per launch of the MFMA convolution kernels (conv_igemm_kernel + conv3x3_halo_kernel), FETCH_SIZE
 corrected as MI355X_MICROARCH.md prescribes for gfx950.
 usage: pmc_traffic.py <pmc_by_kernel.json> <workload> <source label> > profiles/pmc_traffic_<workload>.json"""
@@ -27,7 +27,7 @@ for k, c in d.items():
               "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT", {"sum": 0})["sum"]}
     tot["launches"] += n; tot["fetch"] += f; tot["write"] += w
 out = {"workload": workload,
-       "source": "%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, tests/gpu_pmc.sh)" % label,
+       "source": "%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, tools/measure/gpu_pmc.sh)" % label,
        "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                      "WRITE_SIZE as reported (uncalibrated)",
        "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8 XCDs): matrix-pipe busy fraction "
