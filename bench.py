@@ -118,10 +118,12 @@ def timed_run(w, steps, warmup, world, gather):
     dev = w.device
     res_masks = res_box = None
     if w.refine:
-        res_masks = torch.empty((w.B, steps, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev)
+        res_masks = torch.empty((steps, w.B, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev)
     # per stream and frame: the decoded box (cx, cy, w, h, score, penalty, pscore, best_id) and the
     # 127x127 refine mask logits -- the fixed-size results a tracker keeps (tools/test.py:296-311)
-    res_box = torch.empty((w.B, steps, 8 if w.fused else 30 * 625), dtype=torch.float32 if w.fused else torch.float16,
+    # frame-major [T, B, ...]: each step writes one contiguous row (5 us less per step than [B, T, ...] slices,
+    # profiles/r01_v6_keep_probe.txt)
+    res_box = torch.empty((steps, w.B, 8 if w.fused else 30 * 625), dtype=torch.float32 if w.fused else torch.float16,
                           device=dev)
     for i in range(warmup):
         w.step(i)
@@ -136,12 +138,12 @@ def timed_run(w, steps, warmup, world, gather):
         cls, loc, mask, ref = w.step(i)
         # results kept for the end-of-batch gather (scores/boxes + mask logits)
         if w.fused:
-            res_box[:, i].copy_(cls)                  # `cls` slot carries the decoded box [B,8]
+            res_box[i].copy_(cls)                     # `cls` slot carries the decoded box [B,8]
         else:
-            res_box[:, i, :10 * 625].copy_(cls.reshape(w.B, -1))
-            res_box[:, i, 10 * 625:].copy_(loc.reshape(w.B, -1))
+            res_box[i, :, :10 * 625].copy_(cls.reshape(w.B, -1))
+            res_box[i, :, 10 * 625:].copy_(loc.reshape(w.B, -1))
         if ref is not None:
-            res_masks[:, i].copy_(ref)
+            res_masks[i].copy_(ref)
     ev1.record()
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device wait)
     if world > 1:
