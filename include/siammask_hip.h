@@ -147,7 +147,8 @@ int smk_set_graph_mode(smk_ctx *ctx, int enable);
  *   branch; measured slower)   "concurrency" 0|1 (fork/join between independent launches; measured slower; applies to
  *   contexts created afterwards)
  *   "halo" 0|1|64|128 (3x3 stride-1 convolutions through conv3x3_halo_kernel: off | per-shape choice (default, fp16) |
- *   force that workgroup height)   "chain" 0|1 (fp16: Refine's nine sequential convolutions as one launch,
+ *   force that workgroup height)   "halo_db" 0|1 (double-buffered patch for launches of <= one workgroup per CU)
+ *   "chain" 0|1 (fp16: Refine's nine sequential convolutions as one launch,
  *   refine_chain_kernel; default 1)   "ksplit" 0|1|2|4 (split-K across workgroups with a last-arrival reduction:
  *   off (default; measured a net loss at B=8) | auto for long-K few-tile launches | forced factor).
  * Environment: SMK_CHAIN_CLK=1 makes eager (non-graph) runs print the time workgroup 0 spends in each layer of

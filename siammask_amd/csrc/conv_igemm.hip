@@ -613,7 +613,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT> -- 3x3 stride-1 convolutions with the activation patch
+// conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT, NPATCH> -- 3x3 stride-1 convolutions with the activation patch
 // staged ONCE per channel chunk and shared by all nine taps.
 //
 // The implicit GEMM above re-stages the A rows for every tap (9 x BM x 128 B per 64-channel chunk).
@@ -626,11 +626,14 @@ void conv_igemm_kernel(const ConvBatch cb) {
 // the padded-linear pixel index: BM + a few row wraps + 2*dil*(Wp+1) rows instead of 9*BM.
 // Weights need the chunk-major K order (PackedConv::w_halo).  One patch buffer (single: a new chunk
 // starts with an extra barrier) + an NSLOT-deep weight ring (counted vmcnt inside a chunk) keep the LDS at
-// <= 76 KB, two workgroups per CU.
+// <= 76 KB, two workgroups per CU.  NPATCH = 2 (launches of at most one workgroup per CU, where the LDS is free
+// anyway): the patch is double-buffered -- the next chunk's patch is fetched while the current chunk's nine taps
+// run, the extra barrier and the exposed patch latency (~1 us per chunk boundary) disappear.
 // NHWC epilogue only.  p.buf_lds must be set (SRD range check supplies all zero padding).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT>
-__global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p) {
+template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT, int NPATCH>
+__global__ __launch_bounds__(512, (NPATCH == 2 ? 2 : 4)) void conv3x3_halo_kernel(const ConvParams p) {
+    static_assert(NPATCH == 1 || (NPATCH == 2 && NSLOT >= 3), "double-buffered patch needs a weight ring of >= 3");
     static_assert(WM * WN * WK == 4 && (WK == 1 || WK == 2), "four consumers, K split <= 2");
     typedef Traits<T> TR;
     typedef typename TR::frag_t frag_t;
@@ -643,9 +646,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
     constexpr int A_BYTES = AROWS * KT, W_STAGE = BN * KT;
     constexpr int LDE = 68;
     constexpr int EPI_BYTES = NCW * 64 * LDE * 4;
-    constexpr int LDS_BYTES = CMax<A_BYTES + NSLOT * W_STAGE, EPI_BYTES>::v;
+    constexpr int LDS_BYTES = CMax<NPATCH * A_BYTES + NSLOT * W_STAGE, EPI_BYTES>::v;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    unsigned char *sA = smem, *sW = smem + A_BYTES;
+    unsigned char *sA = smem, *sW = smem + NPATCH * A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -701,10 +704,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
 #pragma unroll
         for (int i = 0; i < RB; ++i) wofs[i] = (unsigned)((size_t)(n0 + lrow + 32 * i) * p.Kpad * sizeof(T)) + slot * 16;
         auto issue_A = [&](int c) {
-            unsigned char *d = sA + pw * 1024;
+            unsigned char *d = sA + (NPATCH == 2 ? (c & 1) * A_BYTES : 0) + pw * 1024;
 #pragma unroll
             for (int i = 0; i < NRND; ++i)
-                if (i * 32 < nrows)                        // (wave-uniform) rounds beyond the footprint are skipped
+                if (NPATCH == 2 || i * 32 < nrows)         // (wave-uniform) rounds beyond the footprint are skipped;
+                                                           // NPATCH == 2 issues all: its vmcnt counts are static
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(d + i * 4096), 16,
                                                              (int)(aoff[i] == OOB ? OOB : aoff[i] + (unsigned)c * KT), 0, 0, 0);
         };
@@ -720,21 +724,26 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
 #pragma unroll
         for (int j = 0; j < NSLOT - 1; ++j)
             if (j < nk) issue_W(j);
-        int tap = 0;                                   // tap index of tile kt
+        int tap = 0, chunk = 0;                        // tap / chunk index of tile kt
         for (int kt = 0; kt < nk; ++kt) {
-            // tile kt landed?  In flight behind it: tiles kt+1 .. kt+NSLOT-2 (and, when kt opens a chunk, the
-            // patch, which is the youngest load -> drain everything)
-            if (tap == 0 || kt + NSLOT - 2 >= nk) wait_vmcnt<0>();
+            // tile kt landed?  In flight behind it: tiles kt+1 .. kt+NSLOT-2, plus
+            //   NPATCH == 1: when kt opens a chunk, the patch, which is the youngest load -> drain everything;
+            //   NPATCH == 2: the next chunk's patch, issued right after barrier(9c) and BEFORE tile 9c+NSLOT-1, so it
+            //                is younger than tile 9c+1 only (loads complete in order): one step allows NRND more
+            if (kt + NSLOT - 2 >= nk || (NPATCH == 1 && tap == 0)) wait_vmcnt<0>();
+            else if (NPATCH == 2 && tap == 1 && chunk + 1 < nch) wait_vmcnt<RB * (NSLOT - 2) + NRND>();
             else wait_vmcnt<RB * (NSLOT - 2)>();
             __builtin_amdgcn_s_barrier();              // barrier(kt): tile kt complete, tile kt-1 released
             asm volatile("" ::: "memory");
+            if (NPATCH == 2 && tap == 0 && chunk + 1 < nch) issue_A(chunk + 1);   // buffer of chunk-1: released by barrier(kt)
             if (kt + NSLOT - 1 < nk) issue_W(kt + NSLOT - 1);
-            if (++tap == 9) {                          // tile kt+1 opens a chunk: the patch is still read by tile kt
+            if (++tap == 9) {                          // tile kt+1 opens a chunk
                 tap = 0;
-                if (kt + 1 < nk) {
+                ++chunk;
+                if (NPATCH == 1 && kt + 1 < nk) {      // single buffer: the patch is still read by tile kt
                     __builtin_amdgcn_s_barrier();      // barrier(x): consumers are done with the patch
                     asm volatile("" ::: "memory");
-                    issue_A((kt + 1) / 9);
+                    issue_A(chunk);
                 }
             }
         }
@@ -758,6 +767,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
         const int fsw = swz<8>(frow);
         const int b_row_off = (wn * 64 + frow) * KT;
         frag_t fa[2][2], fb[2][2];
+        // toff: LDS row offset of the tap, plus the patch buffer's row offset (NPATCH == 2: AROWS rows apart;
+        // AROWS is a multiple of 16, so the swizzle term of a row is the same in both buffers)
         auto read_frags = [&](int wso, int toff, int s, frag_t (&a)[2], frag_t (&bq)[2]) {
             const int sl = (s * WK + wk) * 2 + fhalf;
 #pragma unroll
@@ -780,11 +791,16 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
         __builtin_amdgcn_s_barrier();                  // barrier(0)
         asm volatile("" ::: "memory");
         int tap = 0, toff = 0, wso = 0;                // wso: byte offset of tile kt's weight slot
+        int pbuf = 0;                                  // patch buffer row offset of tile kt's chunk (0 / AROWS)
         read_frags(0, 0, 0, fa[0], fb[0]);
         for (int kt = 0; kt < nk; ++kt) {
             int tapn = tap + 1;
-            if (tapn == 9) tapn = 0;
-            const int toffn = tap_off(tapn);
+            int pbufn = pbuf;
+            if (tapn == 9) {
+                tapn = 0;
+                if (NPATCH == 2) pbufn = AROWS - pbuf;
+            }
+            const int toffn = tap_off(tapn) + pbufn;
             const int wson = wso + W_STAGE == NSLOT * W_STAGE ? 0 : wso + W_STAGE;
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
                     __builtin_amdgcn_sched_barrier(0);
                     if (kt + 1 < nk) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (tapn == 0) {
+                        if (NPATCH == 1 && tapn == 0) {
                             __builtin_amdgcn_s_barrier();      // barrier(x): the patch may be replaced
                             asm volatile("" ::: "memory");
                         }
@@ -819,6 +835,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
             }
             tap = tapn;
             toff = toffn;
+            pbuf = pbufn;
             wso = wson;
         }
     }
@@ -894,7 +911,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const ConvParams p
 
 // host side: eligibility + launch.  Returns 1 when the geometry does not fit (caller falls back to the
 // generic kernel), 0 on success, < 0 on launch errors.  p.wgt must be the chunk-major weight pack.
-template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT>
+template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT, int NPATCH>
 static int launch_halo_t(const ConvParams &p, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int howo = p.Ho * p.Wo, Wp = p.Wl + 2 * p.pad;
@@ -908,7 +925,7 @@ static int launch_halo_t(const ConvParams &p, hipStream_t s) {
     }
     if (worst > AROWS) return 1;
     dim3 grid(p.B * tpi * ((p.Nst + BN - 1) / BN));
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT>), grid, dim3(512), 0, s, p);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT, NPATCH>), grid, dim3(512), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -918,9 +935,17 @@ int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream) {
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.stride_x != 1 || p.ups || p.groups > 1 || p.Ci % ch != 0 ||
         p.out_mode != OUT_NHWC || !p.buf_lds || p.Wo != p.Wl + 2 * p.pad - 2 * p.dil)
         return 1;
-    if (dtype == DT_F16)
-        return bm == 128 ? launch_halo_t<_Float16, 2, 2, 1, 320, 2>(p, s) : launch_halo_t<_Float16, 1, 2, 2, 224, 3>(p, s);
-    return bm == 128 ? launch_halo_t<float, 2, 2, 1, 320, 2>(p, s) : launch_halo_t<float, 1, 2, 2, 224, 3>(p, s);
+    // BM = 64 with more than one channel chunk and at most one workgroup per CU: double-buffered patch (104 KB of
+    // LDS, which such a launch cannot use otherwise).  g_tune.halo_db = 0 keeps the single-buffered kernel.
+    const int ch_n = p.Ci / ch;
+    const long wgs64 = (long)p.B * ((p.Ho * p.Wo + 63) / 64) * ((p.Nst + 127) / 128);
+    const bool db = bm == 64 && g_tune.halo_db && ch_n >= 2 && wgs64 <= 256;
+    if (dtype == DT_F16) {
+        if (bm == 128) return launch_halo_t<_Float16, 2, 2, 1, 320, 2, 1>(p, s);
+        return db ? launch_halo_t<_Float16, 1, 2, 2, 224, 3, 2>(p, s) : launch_halo_t<_Float16, 1, 2, 2, 224, 3, 1>(p, s);
+    }
+    if (bm == 128) return launch_halo_t<float, 2, 2, 1, 320, 2, 1>(p, s);
+    return db ? launch_halo_t<float, 1, 2, 2, 224, 3, 2>(p, s) : launch_halo_t<float, 1, 2, 2, 224, 3, 1>(p, s);
 }
 
 // ---- naive reference kernel: one thread per (m, 4 channels); same params, same packing ----

@@ -86,6 +86,7 @@ struct Tuning {
     int nt_store = 1;          // non-temporal stores for NCHW outputs >= 4 MB (the 63x63 mask logits)
     int halo = 1;              // 3x3 stride-1 convolutions through conv3x3_halo_kernel (0 off, 1 per-shape choice,
                                // 128 / 64 force that workgroup height)
+    int halo_db = 1;           // halo kernel: double-buffered patch when the launch has at most one workgroup per CU
     int chain = 1;             // fp16: Refine's sequential tail as one launch (refine_chain_kernel)
     int ksplit = 0;            // split-K across workgroups: 0 off (default: measured a net loss at B=8, +1 % at B=1,
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
