@@ -71,3 +71,22 @@ def test_torch_port_matches_reference():
         assert sampled_err(g, "mask", mask.numpy()) < 1e-4
         shared = t.track_refine(tuple(int(v) for v in g["shared_pos"]))
         assert rel_err(shared.numpy(), g["refine_shared"]) < 1e-4
+
+
+def test_quant_oracle_tracks_the_reference():
+    """The quantisation-aware oracle (fp16 rounding points of the device path) stays within the loose fp16
+    gates of the reference outputs, and its two Refine summation orders (which branch is stored before the
+    sum: the chain kernel stores v*.2, the per-layer path h*.2) differ by fp16 round-off only."""
+    from oracle.np_oracle import QuantOracle
+    g = load_golden("sharp_damped_b2")        # the fixture the fp16 GPU gates use
+    sd = synth.state_dict("sharp", str(g["fixture"]))
+    z, x = g["z_u8"].astype(np.float64), g["x_u8"].astype(np.float64)
+    refs = {}
+    for order in (True, False):
+        q = QuantOracle(sd, "sharp", refine_sum_in_h=order)
+        q.template(z)
+        cls, loc, mask = q.track_mask(x)
+        refs[order] = q.track_refine(g["best_yx"])
+    assert rel_err(cls, g["cls"]) < 3e-2 and rel_err(loc, g["loc"]) < 3e-2
+    assert rel_err(refs[True], g["refine"]) < 1e-2 and rel_err(refs[False], g["refine"]) < 1e-2
+    assert 0 < rel_err(refs[True], refs[False]) < 5e-3
