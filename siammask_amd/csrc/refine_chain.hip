@@ -13,7 +13,7 @@
 //
 // One pass = implicit GEMM  [pixels x 9*Cin] x [9*Cin x Cout]  on v_mfma_f32_16x16x32_f16:
 //   A fragment: lane -> pixel (lane & 15), eight consecutive K elements (lane >> 4) -- one 16-byte LDS read
-//               of eight channels of one tap (two 8-byte reads of two taps when Cin = 4);
+//               of eight channels of one tap;
 //   B fragment: lane -> output channel (lane & 15), same K slice, from the layer's weights staged in LDS;
 //   C: col = lane & 15 (channel), row = 4*(lane >> 4) + reg (pixel).
 // Activations live in LDS as zero-bordered [(H+2) x (H+2) x C] fp16 images so the 3x3 taps of an ordinary
@@ -182,22 +182,20 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
     float bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = ((const float *)(wl + RC_WROWS * RC_WPITCH))[nt * 16 + fr];
-    // K slice of this lane at step ks starts at k0 = ks*32 + kq*8: its tap (two taps when CIN = 4) and first
-    // channel, as loop-invariant offsets.  In the K padding (tap > 8) the weights are zero, any finite
-    // activation will do: clamp the tap.
-    int kh_[KSTEPS][2], kw_[KSTEPS][2], koff[KSTEPS][2];
+    // K slice of this lane at step ks starts at k0 = ks*32 + kq*8: its tap and first channel as loop-invariant
+    // offsets.  In the K padding (tap > 8) the weights are zero, any finite activation will do: clamp the tap.
+    static_assert(CIN >= 8, "the 4-channel layers go through chain_layer_c4");
+    int kh_[KSTEPS], kw_[KSTEPS], koff[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-        for (int h = 0; h < (CIN >= 8 ? 1 : 2); ++h) {
-            const int k0 = ks * 32 + kq * 8 + h * 4;
-            int tap = k0 / CIN;
-            const int c0 = k0 - tap * CIN;
-            tap = tap > 8 ? 8 : tap;
-            kh_[ks][h] = (tap * 11) >> 5;
-            kw_[ks][h] = tap - 3 * kh_[ks][h];
-            koff[ks][h] = SRC > 0 ? c0 : (kh_[ks][h] * W2 + kw_[ks][h]) * CIN + c0;
-        }
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int k0 = ks * 32 + kq * 8;
+        int tap = k0 / CIN;
+        const int c0 = k0 - tap * CIN;
+        tap = tap > 8 ? 8 : tap;
+        kh_[ks] = (tap * 11) >> 5;
+        kw_[ks] = tap - 3 * kh_[ks];
+        koff[ks] = SRC > 0 ? c0 : (kh_[ks] * W2 + kw_[ks]) * CIN + c0;
+    }
     half8 wf[PRELOAD ? KSTEPS : 1][NT];
     if (PRELOAD) {
 #pragma unroll
@@ -210,24 +208,18 @@ __device__ __forceinline__ void chain_layer(const _Float16 *in, _Float16 *out, c
         int m = mt * 16 + fr;
         m = m < M ? m : M - 1;
         const int oy = m / H, ox = m - oy * H;
-        // element offset (halfs) of this lane's K slice (second half-slice: h = 1) in the bordered input image
+        // element offset (halfs) of this lane's K slice in the bordered input image
         const int pbase = (oy * W2 + ox) * CIN;
-        auto a_off = [&](int ks, int h) {
-            if (SRC > 0) return tab[oy + kh_[ks][h]] + tab[RC_TAB + ox + kw_[ks][h]] + koff[ks][h];
-            return pbase + koff[ks][h];
+        auto a_off = [&](int ks) {
+            if (SRC > 0) return tab[oy + kh_[ks]] + tab[RC_TAB + ox + kw_[ks]] + koff[ks];
+            return pbase + koff[ks];
         };
         floatx4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            half8 a;
-            if (CIN >= 8) {
-                a = *(const half8 *)(in + a_off(ks, 0));
-            } else {
-                const half4 lo = *(const half4 *)(in + a_off(ks, 0)), hi = *(const half4 *)(in + a_off(ks, 1));
-                a = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+            const half8 a = *(const half8 *)(in + a_off(ks));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const half8 b = PRELOAD ? wf[PRELOAD ? ks : 0][nt]
