@@ -288,7 +288,10 @@ def main():
     frames = w.B * world * args.steps
     fps = frames / dt
 
-    roof, recs = roofline(w)
+    try:
+        roof, recs = roofline(w)
+    except Exception as e:  # the profiler pass must never cost the contract line its `value`
+        roof, recs = {"error": str(e)[:200]}, []
     if args.profile_out and rank == 0:
         with open(args.profile_out, "w") as f:
             json.dump({"workload": args.workload, "batch": w.B, "dtype": w.dtype, "layers": recs}, f, indent=1)
