@@ -316,7 +316,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # noqa: BLE001 -- a reported baseline, never a reason to lose the line
+            cpu = {"error": str(e)[:200]}
 
     if rank == 0:
         line = {
