@@ -148,7 +148,7 @@ def test_conv_split_k(cfg, dtype):
                     e = rel_err(y.cpu().numpy(), ref)
                     assert e <= TOL[dtype], "split-K x%d %s %s tile %s rep %d: %.3e" % (sp, cfg, dtype, tile, rep, e)
     finally:
-        _lib.tune(ksplit=1)
+        _lib.tune(ksplit=0)              # the library default
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
