@@ -129,6 +129,12 @@ def timed_run(w, steps, warmup, world, gather):
         w.step(i)
     torch.cuda.synchronize(dev)
     if world > 1:
+        # untimed: one gather of the same tensors, so that RCCL's lazily built channels / registered buffers for this
+        # message size exist before the clock starts (the timed region then contains exactly one steady-state gather)
+        outs = gather.gather(res_box, res_masks) if res_masks is not None else gather.gather(res_box)
+        gather.wait()
+        del outs
+        torch.cuda.synchronize(dev)
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
