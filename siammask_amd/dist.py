@@ -40,7 +40,10 @@ class ResultGather(object):
     """all_gather of per-rank results [S_local, T, ...] -> [world, S_local, T, ...] on every rank.
 
     Every rank must contribute the same shapes (pad the last shard).  On GPUs the collective
-    runs on a dedicated side stream; ``wait()`` makes the current stream wait for it."""
+    runs on a dedicated side stream; ``wait()`` makes the current stream wait for it.
+
+    The inputs must be PRIVATE result buffers (bench.py's Results rows), not the views `track_step` returns: those
+    alias the persistent graph I/O buffers, which the next frame overwrites while the side-stream gather still reads."""
 
     def __init__(self, device=None):
         self.device = device
@@ -53,14 +56,17 @@ class ResultGather(object):
         if world == 1:
             return [t.unsqueeze(0) for t in tensors]
         if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            # outputs are allocated on the CALLER's stream (that is where they are consumed after wait() and where the
+            # caching allocator may recycle them); the side stream's use of them is declared with record_stream
+            ins = [t.contiguous() for t in tensors]
+            outs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in ins]
+            self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                for t in tensors:
-                    t = t.contiguous()
-                    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+                for t, out in zip(ins, outs):
                     dist.all_gather_into_tensor(out, t)
                     t.record_stream(self.side)
-                    outs.append(out)
+                    out.record_stream(self.side)
         else:
             for t in tensors:
                 t = t.contiguous()
