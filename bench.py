@@ -74,7 +74,7 @@ class Workload(object):
         g = np.random.Generator(np.random.PCG64(99 + rank))
         self.pos = torch.from_numpy(g.integers(8, 17, size=(B, 2)).astype(np.int32)).to(device)
         # target size in crop pixels per stream (what siamese_track derives from its state)
-        self.twh = torch.from_numpy(g.uniform(40.0, 110.0, size=(B, 2)).astype(np.float32)).to(device)
+        self.twh = torch.from_numpy(g.uniform(40.0, 110.0, size=(B, 2))).to(device)       # float64 (tools/test.py:230)
         self.model.template(self.z)
         self.fused = fused
         self.last = None
@@ -138,7 +138,7 @@ class Results(object):
         if w.refine:
             self.masks = torch.empty((steps, w.B, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev)
         self.box = torch.empty((steps, w.B, 8 if w.fused else 30 * 625),
-                               dtype=torch.float32 if w.fused else torch.float16, device=dev)
+                               dtype=torch.float64 if w.fused else torch.float16, device=dev)
         self.rows = steps
 
     def tensors(self):

@@ -115,12 +115,15 @@ int smk_refine(smk_ctx *ctx, const int32_t *pos_yx, int pos_on_device, int batch
 /* ---- on-device decode (additive: the tools keep using cls/loc as before) ----
  * smk_decode restates the host code of tools/test.py:205-254 per stream on the device:
  * softmax foreground score, anchor decode (utils/anchors.py:28-51), scale/ratio penalty, cosine
- * window, argmax (lowest index wins ties, like np.argmax), in float64.
- *   target_wh [B,2] device f32: target size in crop pixels (w,h) = target_sz * scale_x (:230)
+ * window, argmax (lowest index wins ties, like np.argmax), with the tool's own precision stages
+ * (NumPy >= 2): float32 softmax / anchor decode / exp / sz() / w-h ratio (:205-220), float64 from
+ * the first division by the float64 target-size scalars on (:231-238).  Pinned against the
+ * unchanged tool (tests/golden/tracker_*.npz, oracle/make_tracker_golden.py).
+ *   target_wh [B,2] device f64: target size in crop pixels (w,h) = target_sz * scale_x (:230)
  *   pos_out   [B,2] device int32 (y,x) = unravel_index(best,(5,25,25))[1:] (:253-254); NULL =
  *             only the ctx-internal position used by a following smk_refine/smk_step is set
- *   box_out   [B,8] device f32: cx, cy, w, h in crop pixels (delta[:,best], :209-212), score,
- *             penalty, pscore, best_id
+ *   box_out   [B,8] device f64: cx, cy, w, h in crop pixels (delta[:,best], :209-212; float32
+ *             values), score (float32 value), penalty, pscore (float64), best_id
  * smk_set_decode_params: anchor (w,h) pairs (5), stride, hp penalty_k / window_influence
  * (config_davis.json); defaults are the reference's config.
  * smk_step = smk_track + smk_decode + smk_refine(at the decoded positions) as ONE captured
@@ -128,9 +131,9 @@ int smk_refine(smk_ctx *ctx, const int32_t *pos_yx, int pos_on_device, int batch
 int smk_set_decode_params(smk_ctx *ctx, const float *anchor_wh, int n_anchor, int stride,
                           double penalty_k, double window_influence);
 int smk_decode(smk_ctx *ctx, const float *cls_dev, const float *loc_dev, int batch,
-               const float *target_wh_dev, int32_t *pos_out_dev, float *box_out_dev, void *stream);
-int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const float *target_wh_dev,
-             float *cls_out, float *loc_out, float *mask_out, float *box_out, float *refine_out,
+               const double *target_wh_dev, int32_t *pos_out_dev, double *box_out_dev, void *stream);
+int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const double *target_wh_dev,
+             float *cls_out, float *loc_out, float *mask_out, double *box_out, float *refine_out,
              void *stream);
 
 /* capture the launch sequences into hipGraphs and replay them (on by default when the

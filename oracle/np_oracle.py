@@ -414,37 +414,52 @@ def generate_anchor(score_size=25, stride=8, ratios=(0.33, 0.5, 1, 2, 3), scales
 
 
 def decode_best(cls, loc, target_sz=(60.0, 80.0), scale_x=1.0, penalty_k=0.04,
-                window_influence=0.4, score_size=25):
-    """Per-item restatement of tools/test.py:205-254: softmax foreground score, anchor
-    decode, scale/ratio penalty, cosine window, argmax -> (best_id, delta_y, delta_x, pscore).
-    cls: [10,25,25], loc: [20,25,25] (one item)."""
-    anchor = generate_anchor(score_size)
-    delta = loc.reshape(4, -1).astype(np.float64)
-    sc = cls.reshape(2, -1).astype(np.float64)
-    e = np.exp(sc - sc.max(axis=0, keepdims=True))
-    score = (e / e.sum(axis=0, keepdims=True))[1]
-    delta[0] = delta[0] * anchor[:, 2] + anchor[:, 0]
-    delta[1] = delta[1] * anchor[:, 3] + anchor[:, 1]
-    delta[2] = np.exp(delta[2]) * anchor[:, 2]
-    delta[3] = np.exp(delta[3]) * anchor[:, 3]
+                window_influence=0.4, score_size=25, lr=1.0):
+    """Per-item restatement of tools/test.py:205-254 WITH THE TOOL'S OWN DTYPES: the arithmetic follows the dtype of
+    the network outputs exactly as the NumPy (>= 2) / torch expressions of the tool do.  For the float32 tensors the
+    tools see this means: float32 softmax (torch, :206), float32 anchor decode incl. np.exp (:209-212; anchors are
+    float32, utils/anchors.py:29), float32 sz() and w/h ratio (:217-220,231-232), and promotion to float64 where a
+    float32 array meets an np.float64 scalar -- the division by sz_wh(target_sz_in_crop) / the ratio of the float64
+    target size (:231-232) -- so penalty, pscore and the window blend are float64 (:234-237).  float64 inputs (the
+    reference run as model.double()) stay float64 throughout.  Pinned bit-for-bit against the unchanged tool by
+    tests/test_decode_reference.py (fixtures from oracle/make_tracker_golden.py).
+    cls: [10,25,25], loc: [20,25,25] (one item) -> (best_id, delta_y, delta_x, pscore)."""
+    import torch
+    cls, loc = np.asarray(cls), np.asarray(loc)
+    anchor = generate_anchor(score_size)                                   # float32 [3125,4] (cx, cy, w, h)
+    delta = loc.reshape(4, -1).copy()                                      # :205
+    sc = torch.from_numpy(np.ascontiguousarray(cls.reshape(2, -1).T))      # :206 view(2,-1).permute(1,0)
+    score = torch.softmax(sc, dim=1)[:, 1].numpy()
+    delta[0, :] = delta[0, :] * anchor[:, 2] + anchor[:, 0]                # :209-212
+    delta[1, :] = delta[1, :] * anchor[:, 3] + anchor[:, 1]
+    delta[2, :] = np.exp(delta[2, :]) * anchor[:, 2]
+    delta[3, :] = np.exp(delta[3, :]) * anchor[:, 3]
 
     def change(r):
-        return np.maximum(r, 1.0 / r)
+        return np.maximum(r, 1. / r)
 
     def sz(w, h):
         pad = (w + h) * 0.5
-        return np.sqrt((w + pad) * (h + pad))
+        sz2 = (w + pad) * (h + pad)
+        return np.sqrt(sz2)
 
-    tw, th = target_sz[0] * scale_x, target_sz[1] * scale_x
-    s_c = change(sz(delta[2], delta[3]) / sz(tw, th))
-    r_c = change((tw / th) / (delta[2] / delta[3]))
-    penalty = np.exp(-(r_c * s_c - 1) * penalty_k)
-    pscore = penalty * score
-    window = np.outer(np.hanning(score_size), np.hanning(score_size))
+    # np.float64 scalars, as in the tool (target_sz is a float64 array, scale_x an np.float64): NOT Python floats,
+    # which NumPy 2 would treat as weak and keep the float32 arrays float32
+    scale_x = np.float64(scale_x)
+    target_sz_in_crop = np.asarray(target_sz, dtype=np.float64) * scale_x   # :230
+    s_c = change(sz(delta[2, :], delta[3, :]) / sz(target_sz_in_crop[0], target_sz_in_crop[1]))     # :231
+    r_c = change((target_sz_in_crop[0] / target_sz_in_crop[1]) / (delta[2, :] / delta[3, :]))       # :232
+    penalty = np.exp(-(r_c * s_c - 1) * penalty_k)                          # :234
+    pscore = penalty * score                                                # :235
+    window = np.outer(np.hanning(score_size), np.hanning(score_size))      # :158-162
     window = np.tile(window.flatten(), 5)
-    pscore = pscore * (1 - window_influence) + window * window_influence
-    best = int(np.argmax(pscore))
-    _, dy, dx = np.unravel_index(best, (5, score_size, score_size))
+    pscore = pscore * (1 - window_influence) + window * window_influence    # :238
+    best = int(np.argmax(pscore))                                           # :239
+    _, dy, dx = np.unravel_index(best, (5, score_size, score_size))         # :253-254
+    pred_in_crop = delta[:, best] / scale_x                                 # :241
     decode_best.last = {"box": np.array([delta[0, best], delta[1, best], delta[2, best], delta[3, best],
-                                          score[best], penalty[best], pscore[best], best], dtype=np.float64)}
+                                          score[best], penalty[best], pscore[best], best], dtype=np.float64),
+                        "pred_in_crop": np.asarray(pred_in_crop, dtype=np.float64),
+                        "lr": float(penalty[best] * score[best] * lr),      # :242
+                        "dtypes": (str(delta.dtype), str(score.dtype), str(penalty.dtype), str(pscore.dtype))}
     return best, int(dy), int(dx), pscore

@@ -105,7 +105,7 @@ struct PackedConv {
 
 constexpr size_t KS_PART_FLOATS = 8u << 20;      // 32 MB: e.g. 256 tiles x 4 parts x 64x128
 constexpr int KS_CNT = 8192;
-constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 4 + 8 * 4 + 4;     // decode_kernel's cross-workgroup scratch
+constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 8 + 8 * 4 + 4;     // decode_kernel's cross-workgroup scratch
 
 static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
 
@@ -1016,7 +1016,7 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 1; }
+int smk_version(void) { return (1 << 16) | 2; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box
 
 const char *smk_last_error(void) { return g_err.c_str(); }
 
@@ -1344,16 +1344,16 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
     return 0;
 }
 
-static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, const float *target_wh, int *pos_out,
-                      float *box_out, hipStream_t s) {
+static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, const double *target_wh, int *pos_out,
+                      double *box_out, hipStream_t s) {
     DecodeParams p;
     memset(&p, 0, sizeof(p));
     p.cls = cls; p.loc = loc; p.target_wh = target_wh; p.window = c->window_dev;
     p.pos_out = pos_out; p.box_out = box_out;
-    {   // [maxB][8] f64 | [maxB][8][8] f32 | [maxB][8] i32 | [maxB] u32
+    {   // [maxB][8] f64 | [maxB][8][8] f64 | [maxB][8] i32 | [maxB] u32
         char *q = (char *)c->dec_scratch;
         p.part_val = (double *)q;             q += (size_t)c->maxB * 8 * 8;
-        p.part_box = (float *)q;              q += (size_t)c->maxB * 64 * 4;
+        p.part_box = (double *)q;             q += (size_t)c->maxB * 64 * 8;
         p.part_idx = (int *)q;                q += (size_t)c->maxB * 8 * 4;
         p.arrived = (unsigned *)q;
     }
@@ -1380,16 +1380,16 @@ int smk_set_decode_params(smk_ctx *c, const float *anchor_wh, int n_anchor, int 
     return 0;
 }
 
-int smk_decode(smk_ctx *c, const float *cls, const float *loc, int B, const float *target_wh, int32_t *pos_out,
-               float *box_out, void *stream) {
+int smk_decode(smk_ctx *c, const float *cls, const float *loc, int B, const double *target_wh, int32_t *pos_out,
+               double *box_out, void *stream) {
     if (!c || !cls || !loc || !target_wh) return fail(SMK_E_ARG, "smk_decode: null argument");
     if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_decode: batch %d not in [1,%d]", B, c->maxB);
     HIPCHK(hipSetDevice(c->device));
     return seq_decode(c, cls, loc, B, target_wh, pos_out ? pos_out : c->pos_dev, box_out, (hipStream_t)stream);
 }
 
-int smk_step(smk_ctx *c, const float *x, int B, int flags, const float *target_wh, float *cls, float *loc,
-             float *mask, float *box_out, float *refine_out, void *stream) {
+int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
+             float *mask, double *box_out, float *refine_out, void *stream) {
     if (!c || !x || !cls || !loc || !target_wh || !box_out) return fail(SMK_E_ARG, "smk_step: null argument");
     if (!c->finalized) return fail(SMK_E_STATE, "smk_step: weights not finalized");
     if (c->template_B == 0) return fail(SMK_E_STATE, "smk_step: smk_template has not been called");

@@ -288,47 +288,69 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
 
 // ------------------------------------------------------------------------------------------
 // decode: softmax foreground score, anchor decode, scale/ratio penalty, cosine window, argmax.
-// Restates the host code of tools/test.py:205-254 (+ anchors of utils/anchors.py:28-51) per
-// stream, in float64 (NumPy >= 2 promotes pscore to float64 there); ties resolve to the lowest
-// index like np.argmax.  Removes the device->host round trip between track_mask and track_refine.
+// Restates the host code of tools/test.py:205-254 (+ anchors of utils/anchors.py:28-51) per stream WITH THE TOOL'S
+// OWN PRECISION STAGES (NumPy >= 2 promotion rules, pinned against the unchanged tool by
+// tests/test_decode_reference.py + tests/test_gpu_e2e.py::test_device_decode_*):
+//   float32: softmax over the two classes (torch, :206), delta*anchor+anchor, exp(delta)*anchor (:209-212; the anchor
+//            table is float32, utils/anchors.py:29), sz(w,h) and w/h (:217-220, :231-232)
+//   float64: from the first division by an np.float64 scalar on -- s_c, r_c, penalty, pscore, the window blend (:231-238)
+// Every operation is a separate IEEE rounding like the NumPy expressions (explicit *_rn intrinsics: no FMA
+// contraction).  The transcendental functions are not bit-identical between libraries (torch's vectorised float32
+// exp, NumPy's SIMD exp, this device's exp): float32 exp is computed here as round_to_float(exp(double)), i.e.
+// correctly rounded, which sits within 1 ulp of either host library.  Ties resolve to the lowest index like np.argmax.
+// Removes the device->host round trip between track_mask and track_refine.
 //
-// The float64 exp / sqrt / divide chain of one candidate is ~800 instructions, so the 3125 candidates
+// The exp / sqrt / divide chain of one candidate is a long dependent sequence, so the 3125 candidates
 // of a stream are spread over A workgroups (one per anchor shape, one candidate per thread).  Each
 // workgroup's winner publishes its score, index and finished box; the workgroup that arrives last
 // (per-stream counter) picks among the A winners and writes the outputs -- no second launch, no
 // recomputation.  The counter is left at zero for the next launch / graph replay.
 // ------------------------------------------------------------------------------------------
 constexpr int DEC_THREADS = 640;                 // >= S*S = 625 candidates of one anchor shape
+__device__ __forceinline__ float exp_f32_cr(float x) { return (float)exp((double)x); }
+
 __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams p) {
     const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S;
     const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
     const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
+    // target_sz_in_crop (float64, :230) and the two float64 scalars derived from it
     const double tw = p.target_wh[2 * b], th = p.target_wh[2 * b + 1];
-    const double tpad = (tw + th) * 0.5;
-    const double tsz = sqrt((tw + tpad) * (th + tpad));
-    const double tratio = tw / th;
+    const double tpad = __dmul_rn(__dadd_rn(tw, th), 0.5);
+    const double tsz = __dsqrt_rn(__dmul_rn(__dadd_rn(tw, tpad), __dadd_rn(th, tpad)));
+    const double tratio = __ddiv_rn(tw, th);
+    const double one_minus_wi = 1.0 - p.window_influence;
     const int ori = -(p.S / 2) * p.stride;
     double best = -1e300;
     int best_i = 0x7fffffff;
-    float box[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    double box[6] = {0., 0., 0., 0., 0., 0.};
     const int rem = threadIdx.x;
     if (rem < SS) {
-        const double c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
-        const double score = 1.0 / (1.0 + exp(c0 - c1));          // softmax(...)[fg]
-        const double aw = p.anchor_w[a], ah = p.anchor_h[a];
-        const double w = exp((double)loc[(2 * p.A + a) * SS + rem]) * aw;
-        const double h = exp((double)loc[(3 * p.A + a) * SS + rem]) * ah;
-        const double pad = (w + h) * 0.5;
-        const double sz = sqrt((w + pad) * (h + pad));
-        double s_c = sz / tsz;  s_c = fmax(s_c, 1.0 / s_c);
-        double r_c = tratio / (w / h);  r_c = fmax(r_c, 1.0 / r_c);
-        const double penalty = exp(-(r_c * s_c - 1.0) * p.penalty_k);
-        best = penalty * score * (1.0 - p.window_influence) + p.window[rem] * p.window_influence;
-        best_i = a * SS + rem;
+        // float32 stage
+        const float c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
+        const float m = fmaxf(c0, c1);
+        const float e0 = exp_f32_cr(__fsub_rn(c0, m)), e1 = exp_f32_cr(__fsub_rn(c1, m));
+        const float score = __fdiv_rn(e1, __fadd_rn(e0, e1));                     // softmax(...)[:, 1]
+        const float aw = p.anchor_w[a], ah = p.anchor_h[a];
         const int y = rem / p.S, x = rem - y * p.S;
-        box[0] = (float)((double)loc[(0 * p.A + a) * SS + rem] * aw + (ori + p.stride * x));
-        box[1] = (float)((double)loc[(1 * p.A + a) * SS + rem] * ah + (ori + p.stride * y));
-        box[2] = (float)w; box[3] = (float)h; box[4] = (float)score; box[5] = (float)penalty;
+        const float cx = __fadd_rn(__fmul_rn(loc[(0 * p.A + a) * SS + rem], aw), (float)(ori + p.stride * x));
+        const float cy = __fadd_rn(__fmul_rn(loc[(1 * p.A + a) * SS + rem], ah), (float)(ori + p.stride * y));
+        const float w = __fmul_rn(exp_f32_cr(loc[(2 * p.A + a) * SS + rem]), aw);
+        const float h = __fmul_rn(exp_f32_cr(loc[(3 * p.A + a) * SS + rem]), ah);
+        const float pad = __fmul_rn(__fadd_rn(w, h), 0.5f);
+        const float sz = __fsqrt_rn(__fmul_rn(__fadd_rn(w, pad), __fadd_rn(h, pad)));
+        const float ratio = __fdiv_rn(w, h);
+        // float64 stage
+        double s_c = __ddiv_rn((double)sz, tsz);
+        s_c = fmax(s_c, __ddiv_rn(1.0, s_c));
+        double r_c = __ddiv_rn(tratio, (double)ratio);
+        r_c = fmax(r_c, __ddiv_rn(1.0, r_c));
+        const double penalty = exp(__dmul_rn(-__dsub_rn(__dmul_rn(r_c, s_c), 1.0), p.penalty_k));
+        const double pscore = __dmul_rn(penalty, (double)score);
+        best = __dadd_rn(__dmul_rn(pscore, one_minus_wi), __dmul_rn(p.window[rem], p.window_influence));
+        if (!(best == best)) best = -1e300;          // NaN candidates never win (np.argmax would pick the first NaN;
+                                                     // the tool's exp overflow case is not a tracked state worth keeping)
+        best_i = a * SS + rem;
+        box[0] = cx; box[1] = cy; box[2] = w; box[3] = h; box[4] = score; box[5] = penalty;
     }
     __shared__ double sv[DEC_THREADS];
     __shared__ int si[DEC_THREADS];
@@ -347,10 +369,11 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     if (best_i == si[0]) {                           // this workgroup's winner (indices are unique)
         // device-coherent (sc1) stores + vmcnt(0) instead of a release fence: an agent-scope fence writes back
         // and invalidates the XCD's whole L2
-        float *pb = p.part_box + ((size_t)b * 8 + a) * 8;
-        for (int q = 0; q < 6; ++q) __hip_atomic_store(pb + q, box[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pb + 6, (float)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pb + 7, (float)best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long *pb = (unsigned long long *)(p.part_box + ((size_t)b * 8 + a) * 8);
+        for (int q = 0; q < 6; ++q)
+            __hip_atomic_store(pb + q, (unsigned long long)__double_as_longlong(box[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pb + 6, (unsigned long long)__double_as_longlong(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pb + 7, (unsigned long long)__double_as_longlong((double)best_i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store((unsigned long long *)(p.part_val + b * 8 + a), (unsigned long long)__double_as_longlong(best),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.part_idx + b * 8 + a, best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,9 +396,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     const int rm = bi - (bi / SS) * SS, y = rm / p.S, x = rm - y * p.S;
     if (p.pos_out) { p.pos_out[2 * b] = y; p.pos_out[2 * b + 1] = x; }
     if (p.box_out) {
-        const float *pb = p.part_box + ((size_t)b * 8 + ba) * 8;
-        float *o = p.box_out + 8 * b;
-        for (int q = 0; q < 8; ++q) o[q] = __hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long *pb = (const unsigned long long *)(p.part_box + ((size_t)b * 8 + ba) * 8);
+        double *o = p.box_out + 8 * b;
+        for (int q = 0; q < 8; ++q)
+            o[q] = __longlong_as_double((long long)__hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

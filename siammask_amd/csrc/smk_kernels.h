@@ -166,14 +166,14 @@ struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; };  
 struct DecodeParams {
     const float *cls;        // [B][2*A][S][S] f32 NCHW
     const float *loc;        // [B][4*A][S][S]
-    const float *target_wh;  // [B][2] target size in crop pixels (w, h) = target_sz * scale_x
+    const double *target_wh; // [B][2] f64 target size in crop pixels (w, h) = target_sz * scale_x (tools/test.py:230)
     const double *window;    // [S*S] cosine window (outer(hanning, hanning))
     int *pos_out;            // [B][2] (y, x) of the best anchor position
-    float *box_out;          // [B][8] cx, cy, w, h (crop pixels), score, penalty, pscore, best_id
+    double *box_out;         // [B][8] f64: cx, cy, w, h (crop pixels; float32 values), score (float32 value), penalty, pscore, best_id
     // scratch for the cross-workgroup argmax: winners per (stream, anchor shape); `arrived` starts at 0
     double *part_val;        // [B][8]
     int *part_idx;           // [B][8]
-    float *part_box;         // [B][8][8]
+    double *part_box;        // [B][8][8]
     unsigned *arrived;       // [B]
     int B, A, S, stride;
     float anchor_w[8], anchor_h[8];

@@ -121,13 +121,13 @@ class Custom(nn.Module):
         self._weights_dirty = True
 
     # -- context ----------------------------------------------------------------------------
-    def _ensure(self, x, batch):
+    def _ensure(self, x, batch, grow=False):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise RuntimeError("siammask_amd runs on the MI355X only: expected a CUDA(HIP) tensor, got %s"
                                % (x.device if isinstance(x, torch.Tensor) else type(x)))
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         L = _lib.lib()
-        self._ensure_ctx(dev, batch)
+        self._ensure_ctx(dev, batch, grow)
         if self._weights_dirty:
             sd = [(name, np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy()))
                   for name, t in self.state_dict().items() if not name.endswith("num_batches_tracked")]
@@ -195,9 +195,18 @@ class Custom(nn.Module):
         self._tracked = 0
         self.zf = None
 
-    def _ensure_ctx(self, dev, batch):
+    def _ensure_ctx(self, dev, batch, grow=True):
+        """grow=True (template(), load_packed()): a larger batch or another device re-creates the context -- the cached
+        template goes with it, which is fine because a new template follows.  grow=False (track*, decode): the
+        context is never silently destroyed under a cached template; a batch beyond max_batch is an error."""
         L = _lib.lib()
         if self._ctx is not None and (dev != self._ctx_device or batch > self._max_batch):
+            if not grow:
+                if dev != self._ctx_device:
+                    raise RuntimeError("input is on cuda:%s but this model's context (weights, cached template) lives on "
+                                       "cuda:%s; call template() on the new device first" % (dev, self._ctx_device))
+                raise RuntimeError("batch %d exceeds this context's max_batch %d; call template() with the new batch "
+                                   "first (or construct with max_batch=%d)" % (batch, self._max_batch, batch))
             self._destroy()
         if self._ctx is None:
             self._max_batch = max(self._max_batch, batch)
@@ -227,10 +236,10 @@ class Custom(nn.Module):
         except Exception:
             pass
 
-    def _buf(self, key, shape, device):
+    def _buf(self, key, shape, device, dtype=torch.float32):
         t = self._io.get(key)
-        if t is None or tuple(t.shape) != tuple(shape) or t.device != device:
-            t = torch.empty(shape, dtype=torch.float32, device=device)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != device or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=device)
             self._io[key] = t
         return t
 
@@ -244,16 +253,16 @@ class Custom(nn.Module):
             return buf
         return x.to(torch.float32).contiguous()
 
-    def _out(self, key, shape, device):
+    def _out(self, key, shape, device, dtype=torch.float32):
         if self._graph:
-            return self._buf(key, shape, device)
-        return torch.empty(shape, dtype=torch.float32, device=device)
+            return self._buf(key, shape, device, dtype)
+        return torch.empty(shape, dtype=dtype, device=device)
 
     # -- the reference surface ------------------------------------------------------------------
     def template(self, template):
         """custom.py:173-174 -- caches the template features (and conv_kernel(zf)) on device."""
         B = template.shape[0]
-        self._ensure(template, B)
+        self._ensure(template, B, grow=True)
         with torch.cuda.device(self._ctx_device):
             z = self._stage_in("z", template, spec.TEMPLATE_SIZE)
             _lib.check(_lib.lib().smk_template(self._ctx, z.data_ptr(), B, _lib.current_stream_ptr()))
@@ -290,17 +299,27 @@ class Custom(nn.Module):
 
     # -- additive API: on-device decode + fused per-frame step -------------------
     def set_tracker_hp(self, penalty_k=0.04, window_influence=0.4):
-        """hp of the host decode (config_*.json 'hp'); anchors come from self.anchors
-        (utils/anchors.py:40-50: integer-truncated ws/hs times scale)."""
+        """hp of the host decode (config_*.json 'hp'); anchors come from self.anchors exactly as
+        utils/anchors.py:38-50 builds them: ws/hs integer-truncated, or rounded to `round_dight` decimals when
+        anchors['round_dight'] > 0; stored float32 like the reference's anchor table (:29)."""
         import math
         self._hp = (float(penalty_k), float(window_influence))
         wh = []
         size = self.anchors["stride"] ** 2
+        rd = int(self.anchors.get("round_dight", 0) or 0)
+        if int(self.anchors.get("anchor_density", 1) or 1) != 1:
+            raise ValueError("anchor_density != 1 is not supported by the device decode (config_*.json use 1)")
         for r in self.anchors["ratios"]:
-            ws = int(math.sqrt(size * 1.0 / r))
-            hs = int(ws * r)
+            if rd > 0:
+                ws = round(math.sqrt(size * 1. / r), rd)
+                hs = round(ws * r, rd)
+            else:
+                ws = int(math.sqrt(size * 1. / r))
+                hs = int(ws * r)
             for sc in self.anchors["scales"]:
-                wh += [ws * sc, hs * sc]
+                # the table stores corners (-w/2, -h/2, w/2, h/2) in float32 and the tools take x2-x1, y2-y1
+                w2, h2 = np.float32(ws * sc * 0.5), np.float32(hs * sc * 0.5)
+                wh += [w2 - (-w2), h2 - (-h2)]
         self._anchor_wh = np.asarray(wh, dtype=np.float32)
         self._hp_dirty = True
 
@@ -315,16 +334,19 @@ class Custom(nn.Module):
 
     def decode(self, cls, loc, target_wh):
         """Device restatement of tools/test.py:205-254 for B streams.
-        target_wh: [B,2] float32 CUDA tensor, target size in crop pixels (w,h) = target_sz*scale_x.
-        -> (pos [B,2] int32 (y,x), box [B,8] float32: cx,cy,w,h,score,penalty,pscore,best_id)."""
+        target_wh: [B,2] tensor (any float dtype / device; used as float64 like the tool's target_sz*scale_x, :230),
+        target size in crop pixels (w,h).
+        -> (pos [B,2] int32 (y,x), box [B,8] float64: cx,cy,w,h,score,penalty,pscore,best_id)."""
         B = cls.shape[0]
+        if cls.dtype != torch.float32 or loc.dtype != torch.float32:
+            raise ValueError("decode() takes the float32 cls/loc the network returns")
         self._ensure(cls, B)
         self._push_hp()
         dev = cls.device
         with torch.cuda.device(self._ctx_device):
             pos = torch.empty((B, 2), dtype=torch.int32, device=dev)
-            box = torch.empty((B, 8), dtype=torch.float32, device=dev)
-            twh = target_wh.to(dev, torch.float32).contiguous()
+            box = torch.empty((B, 8), dtype=torch.float64, device=dev)
+            twh = target_wh.to(dev, torch.float64).contiguous()
             _lib.check(_lib.lib().smk_decode(self._ctx, cls.contiguous().data_ptr(), loc.contiguous().data_ptr(), B,
                                             twh.data_ptr(), pos.data_ptr(), box.data_ptr(), _lib.current_stream_ptr()))
         return pos, box
@@ -334,7 +356,8 @@ class Custom(nn.Module):
         the decoded positions, replayed as ONE captured graph.
         -> dict(cls, loc, mask, box [B,8], refine [B,16129] or None).  With graph replay the
         returned tensors are views of persistent I/O buffers (valid until the next call).
-        stage=False: ``search`` / ``target_wh`` are caller-owned persistent float32 CUDA buffers
+        ``box`` is float64 [B,8] (cx, cy, w, h, score, penalty, pscore, best_id), target_wh float64 (:230).
+        stage=False: ``search`` (float32) / ``target_wh`` (float64) are caller-owned persistent CUDA buffers
         (e.g. a ring of pre-staged crops); they are read in place (no staging copy) and the
         captured graph is keyed on their addresses."""
         if self.zf is None:
@@ -361,19 +384,19 @@ class Custom(nn.Module):
         with torch.cuda.device(self._ctx_device):
             if stage:
                 x = self._stage_in("x", search, spec.SEARCH_SIZE)
-                twh = self._buf("twh", (B, 2), dev)
+                twh = self._buf("twh", (B, 2), dev, torch.float64)
                 twh.copy_(target_wh)
             else:
                 if (search.dtype != torch.float32 or not search.is_contiguous() or tuple(search.shape[1:]) !=
                         (3, spec.SEARCH_SIZE, spec.SEARCH_SIZE)):
                     raise ValueError("stage=False needs a contiguous float32 [B,3,255,255] tensor")
-                if target_wh.dtype != torch.float32 or not target_wh.is_contiguous() or not target_wh.is_cuda:
-                    raise ValueError("stage=False needs a contiguous float32 CUDA target_wh [B,2]")
+                if target_wh.dtype != torch.float64 or not target_wh.is_contiguous() or not target_wh.is_cuda:
+                    raise ValueError("stage=False needs a contiguous float64 CUDA target_wh [B,2]")
                 x, twh = search, target_wh
             cls = self._out("cls", (B, 2 * A, S, S), dev)
             loc = self._out("loc", (B, 4 * A, S, S), dev)
             mask = self._out("mask", (B, spec.MASK_OUT ** 2, S, S), dev) if want_mask else None
-            box = self._out("box", (B, 8), dev)
+            box = self._out("box", (B, 8), dev, torch.float64)
             ref = self._out("refine", (B, spec.REFINE_OUT ** 2), dev) if refine else None
             args = (x.data_ptr(), B, flags, twh.data_ptr(), cls.data_ptr(), loc.data_ptr(),
                     mask.data_ptr() if mask is not None else None, box.data_ptr(),

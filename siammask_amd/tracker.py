@@ -71,8 +71,9 @@ class DeviceTracker(object):
         return self.state
 
     # -- siamese_track (tools/test.py:173-311) ---------------------------------------------------
-    def track(self, frame, want_mask=True):
+    def track(self, frame, want_mask=True, keep_crop=False):
         p, st = self.p, self.state
+        want_mask = want_mask and self.model.variant != "rpn"         # siamrpn has no mask branch (mask_enable=False)
         pos, sz = st["target_pos"], st["target_sz"]
         B = pos.shape[0]
         s_x = np.empty(B)
@@ -88,9 +89,9 @@ class DeviceTracker(object):
             r = round(s_x[b])
             crop_box.append([pos[b, 0] - r / 2, pos[b, 1] - r / 2, r, r])
         x = preproc.crop_batch(frame, pos, p.instance_size, [round(v) for v in s_x], st["avg_chans"])
-        twh = torch.from_numpy((sz * scale_x[:, None]).astype(np.float32)).to(x.device)   # target_sz_in_crop (:230)
+        twh = torch.from_numpy(sz * scale_x[:, None]).to(x.device)    # target_sz_in_crop, float64 (:230)
         out = self.model.track_step(x, twh, refine=self.refine and want_mask, mask_head=not self.refine)
-        box = out["box"].cpu().numpy().astype(np.float64)             # cx, cy, w, h, score, penalty, pscore, best_id
+        box = out["box"].cpu().numpy()                                # float64: cx, cy, w, h, score, penalty, pscore, best_id
         best = box[:, 7].astype(np.int64)
         ss = p.score_size
         delta_y, delta_x = (best % (ss * ss)) // ss, best % ss        # np.unravel_index (:253-254)
@@ -115,8 +116,8 @@ class DeviceTracker(object):
         new_pos[:, 1] = np.clip(new_pos[:, 1], 0, st["im_h"])
         new_sz[:, 0] = np.clip(new_sz[:, 0], 10, st["im_w"])
         new_sz[:, 1] = np.clip(new_sz[:, 1], 10, st["im_h"])
-        st.update(target_pos=new_pos, target_sz=new_sz, score=box[:, 4].copy(), mask=masks,
-                  delta_yx=np.stack([delta_y, delta_x], 1), crop_box=crop_box)
+        st.update(target_pos=new_pos, target_sz=new_sz, score=box[:, 4].copy(), mask=masks, best_id=best,
+                  delta_yx=np.stack([delta_y, delta_x], 1), crop_box=crop_box, x_crop=x.clone() if keep_crop else None)
         return st
 
 
