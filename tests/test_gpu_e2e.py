@@ -401,6 +401,7 @@ def test_bench_configuration_b64(dtype, force):
     # every stream got its own result (no stream aliasing inside the big tiles): distinct inputs -> distinct logits
     r = out["refine"].cpu().numpy()
     assert len({r[b].tobytes() for b in range(B)}) == B
+    os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "e2e_bench_b64_%s_force%d.json" % (dtype, force)), "w") as f:
         json.dump(errs, f)
     bad = {k: v for k, v in errs.items() if not v <= tol}
