@@ -93,6 +93,7 @@ struct ConvPart {
 struct PackedConv {
     void *w = nullptr;       // device [rows][Kpad] dtype
     void *w_halo = nullptr;  // same weights, K ordered (chunk, kh, kw, c in chunk) for conv3x3_halo_kernel (3x3 only)
+    void *w_frag = nullptr;  // same weights in MFMA-fragment order for conv_wreg_kernel (f16 only)
     float *bias = nullptr;   // device [rows] f32
     int N = 0;               // real output channels per group
     int rows = 0;            // total rows (all groups), multiple of NPAD_ALIGN
@@ -122,6 +123,25 @@ static void pack_rows(std::vector<float> &dst, int row0, int Kpad, const float *
                 }
 }
 
+// fragment-order copy of an f16 pack for conv_wreg_kernel: one contiguous KB per (32 rows, 16 k) MFMA operand --
+// [rows/32][Kpad/16][lane 0..63][8 halves] with lane = (n % 32) + 32 * ((k % 16) / 8), element e = k % 8
+static int upload_frag_pack(PackedConv &pc, const std::vector<float> &rows_f32, int dtype) {
+    if (dtype != DT_F16 || pc.rows % 32 || pc.Kpad % 16) return 0;
+    const int KS16 = pc.Kpad / 16;
+    std::vector<_Float16> h((size_t)pc.rows * pc.Kpad);
+    for (int n = 0; n < pc.rows; ++n) {
+        const float *src = rows_f32.data() + (size_t)n * pc.Kpad;
+        const size_t blk = (size_t)(n / 32) * KS16;
+        for (int k = 0; k < pc.Kpad; ++k) {
+            const int lane = (n % 32) + 32 * ((k % 16) / 8);
+            h[((blk + k / 16) * 64 + lane) * 8 + k % 8] = (_Float16)src[k];
+        }
+    }
+    HIPCHK(hipMalloc(&pc.w_frag, h.size() * 2));
+    HIPCHK(hipMemcpy(pc.w_frag, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, const std::vector<float> &bias,
                          int dtype) {
     const size_t n = rows_f32.size();
@@ -135,7 +155,7 @@ static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, con
     }
     HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * 4));
     HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-    return 0;
+    return upload_frag_pack(pc, rows_f32, dtype);       // derived copy for conv_wreg_kernel (f16 only)
 }
 
 // chunk-major copy of a 3x3 pack: k = (tap*Ci + c)  ->  k' = ((c / CH)*9 + tap)*CH + c % CH
@@ -517,6 +537,7 @@ struct ConvOpt {
     int algo_naive = 0;
     int tile_code = 0;
     int halo = 0;             // 128 / 64: force the halo kernel with this BM (per-op tests)
+    int wreg = 0;             // 1..6: force conv_wreg_kernel with this tile code (per-op tests, micro-benchmark)
 };
 
 static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, const Act *out, int B,
@@ -524,6 +545,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     memset(&p, 0, sizeof(p));
     p.in = in.p;
     p.wgt = pc.w;
+    p.wgt_frag = pc.w_frag;
     p.bias = pc.bias;
     p.pos = o.pos;
     p.B = B;
@@ -628,6 +650,18 @@ static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt 
     return tiles128 >= 300 ? 128 : 64;
 }
 
+// conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
+// (64x256, 64x128, 64x64, 128x256, 128x128, 128x64) or 0.
+static const int WREG_TILE[7][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}};
+static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
+    if (o.algo_naive || !conv_wreg_eligible(p, dtype)) return 0;
+    if (o.wreg) return o.wreg;
+    if (g_tune.wreg >= 2) return g_tune.wreg - 1;
+    if (!g_tune.wreg) return 0;
+    return 0;                                  // per-shape choice: fitted below once measured
+}
+static int wreg_stages() { return g_tune.wreg_stages ? g_tune.wreg_stages : 3; }
+
 static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, int B, const ConvOpt &o,
                     hipStream_t s) {
     auto it = c->conv.find(id);
@@ -649,7 +683,20 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     int rc = 1;
     int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
     if (bm && !o.halo && conv_ksplit(p, c->dtype, t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
-    if (bm) {
+    const int wr = (o.halo || (bm && !o.wreg && g_tune.wreg < 2)) ? 0 : wreg_choice(p, o, c->dtype);
+    if (wr) {
+        // weights straight into registers, activations through LDS
+        ConvBatch cb;
+        cb.n = 1;
+        cb.p[0] = p;
+        char kw_[64];
+        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(c->dtype), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages());
+        ProfScope ps(c, s, id, kw_, flop, bytes);
+        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
+        if (rc == 1) ps.cancel();
+        else bm = 0;
+    }
+    if (bm && rc == 1) {
         // 3x3 stride-1: the activation patch is staged once per channel chunk and shared by the nine taps
         ConvParams ph = p;
         ph.wgt = it->second.w_halo;
@@ -690,6 +737,16 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
     if (c->prof || cb.n == 1 || !g_tune.merge || (split_for_halo && n_halo)) {   // per-layer attribution while profiling
         for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
         return 0;
+    }
+    {
+        int wr = wreg_choice(cb.p[lead], jobs[lead].o, c->dtype);
+        for (int i = 0; i < cb.n && wr; ++i)
+            if (!wreg_choice(cb.p[i], jobs[i].o, c->dtype)) wr = 0;
+        if (wr) {
+            const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
+            if (rc == 0) return 0;
+            if (rc != 1) return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
+        }
     }
     const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], c->dtype);
     if (launch_conv_mfma_batch(cb, c->dtype, t, s))
@@ -1064,7 +1121,7 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf) hipFree(kv.second);
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->ks_part) hipFree(c->ks_part);
@@ -1098,7 +1155,7 @@ int smk_finalize_weights(smk_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
     c->conv.clear();
     int rc = build_weights(c);
     if (rc) return rc;
@@ -1179,7 +1236,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
     c->conv.clear();
     c->finalized = false;
     for (int i = 0; i < h.n_conv; ++i) {
@@ -1187,7 +1244,12 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
         PackEntry en;
         memcpy(&en, p, sizeof(en)); p += sizeof(en);
         en.id[sizeof(en.id) - 1] = 0;
-        if (en.rows < 1 || en.Kpad < 1 || en.rows % NPAD_ALIGN || en.Kpad % KPAD_ALIGN || en.K > en.Kpad)
+        const int en_kw = en.kw ? en.kw : en.k;
+        if (en.rows < 1 || en.Kpad < 1 || en.rows % NPAD_ALIGN || en.Kpad % KPAD_ALIGN || en.K > en.Kpad ||
+            en.K < 1 || en.Ci < 8 || en.Ci % 8 || en.k < 1 || en.k > 15 || en_kw < 1 || en_kw > 15 ||
+            en.K != en.k * en_kw * en.Ci || en.groups < 1 || en.group_rows < 1 || en.group_rows % NPAD_ALIGN ||
+            (long)en.groups * en.group_rows != en.rows || en.N < 1 || en.N > en.group_rows || en.alg_k < 0 ||
+            en.alg_k > en.K || (long)en.rows * en.Kpad > (1L << 28))
             return fail(SMK_E_WEIGHT, "smk_import_packed: entry %s has bad geometry", en.id);
         const size_t wb = (size_t)en.rows * en.Kpad * esize(c->dtype), bb = (size_t)en.rows * 4;
         if (p + wb + bb > end) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated data of %s", en.id);
@@ -1196,11 +1258,12 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
         pc.Ci = en.Ci; pc.k = en.k; pc.K = en.K; pc.Kpad = en.Kpad; pc.kw = en.kw; pc.alg_k = en.alg_k;
         HIPCHK(hipMalloc(&pc.w, wb));
         HIPCHK(hipMemcpy(pc.w, p, wb, hipMemcpyHostToDevice));
-        if (pc.groups == 1) {                      // chunk-major copy for the halo kernel (derived, not stored)
+        {   // derived copies (not stored in the blob): chunk-major for the halo kernel, fragment order for conv_wreg_kernel
             std::vector<float> rf((size_t)en.rows * en.Kpad);
             if (c->dtype == DT_F16) { const _Float16 *h = (const _Float16 *)p; for (size_t i = 0; i < rf.size(); ++i) rf[i] = (float)h[i]; }
             else memcpy(rf.data(), p, wb);
-            CHK(upload_halo_pack(pc, rf, c->dtype));
+            if (pc.groups == 1) CHK(upload_halo_pack(pc, rf, c->dtype));
+            CHK(upload_frag_pack(pc, rf, c->dtype));
         }
         p += wb;
         HIPCHK(hipMalloc((void **)&pc.bias, bb));
@@ -1286,6 +1349,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
+    else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;
     else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
@@ -1520,6 +1585,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     CHK(upload_packed(pc, rows, bias, dtype));
     TmpBufs tmp;
     tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
+    if (pc.w_frag) tmp.v.push_back(pc.w_frag);
     const size_t es = esize(dtype);
     CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
     CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C, 0};
@@ -1563,7 +1629,15 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
     }
     int rc;
-    if (o.halo) {
+    if (mode == 5) {                                   // conv_wreg_kernel, tile code 1..6 in the low tile bits
+        const int wr = o.tile_code & 15;
+        if (wr < 1 || wr > 6) return fail(SMK_E_ARG, "smk_op_conv2d_ex: wreg tile code 1..6");
+        ConvBatch cb;
+        cb.n = 1;
+        cb.p[0] = p;
+        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], ((o.tile_code >> 6) & 3) == 3 ? 4 : 3, s);
+        if (rc == 1) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry / dtype is not eligible for conv_wreg_kernel");
+    } else if (o.halo) {
         ConvParams ph = p;
         ph.wgt = pc.w_halo;
         rc = launch_conv_halo(ph, dtype, o.halo, s);
@@ -1750,7 +1824,22 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
     CHK(conv_params(&fake, pc, in, mode == 2 ? nullptr : &out, g->B, o, p));
     const TileChoice t = tile_from_code(o.tile_code, p, dtype);
     const int halo_bm = mode == 4 ? ((o.tile_code & 15) == 1 ? 128 : 64) : 0;     // timing only: K order is irrelevant
-    auto launch = [&]() { return halo_bm ? launch_conv_halo(p, dtype, halo_bm, s) : launch_conv_mfma(p, dtype, t, s); };
+    const int wr = mode == 5 ? (o.tile_code & 15) : 0;
+    if (mode == 5) {
+        if (wr < 1 || wr > 6) return fail(SMK_E_ARG, "smk_bench_conv: wreg tile code 1..6");
+        p.wgt_frag = p.wgt;                              // timing only: the fragment order is irrelevant
+        if (!conv_wreg_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_wreg_kernel");
+    }
+    const int wr_stages = ((o.tile_code >> 6) & 3) == 3 ? 4 : 3;
+    auto launch = [&]() {
+        if (wr) {
+            ConvBatch cb;
+            cb.n = 1;
+            cb.p[0] = p;
+            return launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wr_stages, s);
+        }
+        return halo_bm ? launch_conv_halo(p, dtype, halo_bm, s) : launch_conv_mfma(p, dtype, t, s);
+    };
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

@@ -23,6 +23,8 @@ constexpr int KPAD_ALIGN = 128;   // elements; a multiple of every K-tile size (
 struct ConvParams {
     const void *in;        // NHWC storage tensor [B][Hs][Ws][Cs] (dtype)
     const void *wgt;       // [Npad][Kpad] (dtype)
+    const void *wgt_frag;  // f16 only: the same matrix in MFMA-fragment order (conv_wreg_kernel), or nullptr:
+                           //   [Npad/32][Kpad/16][64 lanes][8 halves], lane = (n % 32) + 32 * ((k % 16) / 8)
     const float *bias;     // [Npad] f32 (BN beta' or conv bias; zero padded)
     const void *res;       // optional residual, NHWC [B][Ho][Wo][res_Cs] (dtype)
     void *out;             // NHWC dtype  or  NCHW f32
@@ -96,6 +98,9 @@ struct Tuning {
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
+    int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
+                               // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
+    int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
 };
 extern Tuning g_tune;
 
@@ -210,6 +215,10 @@ int conv_ksplit(const ConvParams &p, int dtype, const TileChoice &t);
 // 3x3 stride-1 convolution with the activation patch shared by the nine taps (chunk-major weight pack);
 // returns 1 when the geometry is not eligible
 int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);
+// weights straight into registers (conv_wreg.hip): f16, NHWC epilogue, p.wgt_frag set; tile bm in {64,128} x bn in
+// {64,128,256}; returns 1 when a problem of the batch is not eligible
+bool conv_wreg_eligible(const ConvParams &p, int dtype);
+int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stream);
 // the sequential tail of Refine (h2, post0, h1, post1, h0, post2) as one launch, fp16 only (refine_chain.hip)
 struct RefineChainLayer {
     const void *w;         // packed weights [rows][Kpad] fp16, K = (tap, channel of a Ci-channel image)

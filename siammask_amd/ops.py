@@ -11,7 +11,8 @@ import torch
 
 from . import _lib
 
-ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4}
+ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4, "wreg": 5}
+WREG_TILE = {(64, 256): 1, (64, 128): 2, (64, 64): 3, (128, 256): 4, (128, 128): 5, (128, 64): 6}
 TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5}
 
 
@@ -24,6 +25,11 @@ def _chk_cuda(*ts):
 def tile_code(tile=None, kt=0, stages=0):
     """second byte of `algo`: tile override, K-tile bytes (0|128|256), LDS ring depth (0|2|3|4)"""
     return TILE[tile] | ({0: 0, 128: 1, 256: 2}[kt] << 4) | ({0: 0, 2: 1, 3: 2, 4: 3}[stages] << 6)
+
+
+def wreg_code(tile, stages=0):
+    """second byte of `algo` for algo='wreg': conv_wreg_kernel tile (bm, bn) and A-ring depth (0|3|4)"""
+    return WREG_TILE[tuple(tile)] | ({0: 0, 3: 2, 4: 3}[stages] << 6)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=1, dtype="f32",
@@ -55,7 +61,7 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=
     y = torch.empty((B, g.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     p = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
     r = None if res is None else res.contiguous().float()
-    code = ALGO[algo] | (tile_code(tile, kt, stages) << 8)
+    code = ALGO[algo] | ((wreg_code(tile, stages) if algo == "wreg" else tile_code(tile, kt, stages)) << 8)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().smk_op_conv2d_ex(
@@ -88,7 +94,7 @@ def maxpool3x3s2(x, dtype="f32"):
 
 
 def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=None, kt=0, stages=0,
-               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50, halo=False):
+               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50, halo=False, wreg=False):
     """average microseconds per launch of the MFMA conv kernel on this geometry (smk_bench_conv)"""
     g = _lib.ConvGeom()
     g.B, g.Cin, g.H, g.W = B, Cin, H, W
@@ -98,7 +104,10 @@ def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=
     if win is not None:
         g.win, g.Hl, g.Wl = 1, win[0], win[1]
     us = ctypes.c_float(0.0)
-    code = (4 if halo else (2 if nchw else 0)) | (tile_code(tile, kt, stages) << 8)
+    if wreg:
+        code = 5 | (wreg_code(tile, stages) << 8)
+    else:
+        code = (4 if halo else (2 if nchw else 0)) | (tile_code(tile, kt, stages) << 8)
     _lib.check(_lib.lib().smk_bench_conv(_lib.DTYPE[dtype], code, ctypes.byref(g), int(bool(res)), iters,
                                          ctypes.byref(us), _lib.current_stream_ptr()))
     return us.value

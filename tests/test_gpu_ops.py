@@ -254,3 +254,67 @@ def test_maxpool(dtype):
         ref = O.maxpool_3x3_s2_p1(_q(x, dtype))
         y = ops.maxpool3x3s2(torch.from_numpy(x).cuda(), dtype=dtype).cpu().numpy()
         assert y.shape == ref.shape and rel_err(y, ref) == 0.0   # max is exact
+
+
+WREG_TILES = ((64, 256), (64, 128), (64, 64), (128, 256), (128, 128), (128, 64))
+WREG_CASES = [
+    # cin, cout, k, stride, pad, dil, hw, B, residual
+    (64, 64, 1, 1, 0, 1, 31, 2, False),      # short K (one 128-element pad: two K tiles)
+    (256, 1024, 1, 1, 0, 1, 15, 1, True),    # bottleneck conv3 + residual + ReLU, wide N
+    (1024, 256, 1, 1, 0, 1, 15, 1, False),   # bottleneck conv1, long K
+    (256, 256, 3, 1, 2, 2, 15, 1, False),    # l3 3x3 d2 p2 (tap-uniform K tiles)
+    (128, 128, 3, 2, 0, 1, 31, 1, False),    # 3x3 s2 p0
+    (512, 96, 3, 1, 1, 1, 9, 3, True),       # long K, N = 96: tile overhang beyond the packed rows (SRD zero fill)
+    (256, 10, 1, 1, 0, 1, 25, 2, False),     # N = 10
+    (32, 16, 3, 1, 1, 1, 15, 2, False),      # Ci < K tile: taps straddle K tiles (per-lane tap decode)
+    (3, 64, 7, 2, 0, 1, 63, 2, False),       # Cin 3 -> 8, K = 392 -> 512
+]
+
+
+@pytest.mark.parametrize("cfg", WREG_CASES)
+def test_conv_wreg_kernel(cfg):
+    """conv_wreg_kernel (weights in MFMA-fragment order straight into registers, activations through LDS) against the
+    oracle: every workgroup shape x both A-ring depths, bias + ReLU (+ residual), M tails, N overhang."""
+    ops = _ops()
+    cin, cout, k, stride, pad, dil, hw, B, with_res = cfg
+    rng = np.random.default_rng(hash(cfg) & 0xffff)
+    x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k), _rand(rng, cout)
+    ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ref = O.conv2d(_q(x, "f16"), _q(w, "f16"), b.astype(np.float64), stride, pad, dil)
+    rd = None
+    if with_res:
+        res = _rand(rng, B, cout, ho, ho)
+        ref = ref + _q(res, "f16")
+        rd = torch.from_numpy(res).cuda()
+    ref = np.maximum(ref, 0)
+    xd = torch.from_numpy(x).cuda()
+    errs = {}
+    for tile in WREG_TILES:
+        for stages in (3, 4):
+            y = ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16", algo="wreg", tile=tile,
+                           stages=stages)
+            errs["%dx%d/s%d" % (tile[0], tile[1], stages)] = rel_err(y.cpu().numpy(), ref)
+    bad = {a: e for a, e in errs.items() if not e <= TOL["f16"]}
+    assert not bad, "wreg %s: %s (all: %s)" % (cfg, bad, errs)
+
+
+def test_conv_wreg_windows_and_upsample():
+    """the gather features the Refine convolutions use (per-stream windows, nearest upsampling) through conv_wreg_kernel"""
+    ops = _ops()
+    rng = np.random.default_rng(16)
+    f = _rand(rng, 3, 64, 31, 31)
+    w = _rand(rng, 32, 64, 3, 3) / 24
+    pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
+    fp = np.pad(_q(f, "f16"), ((0, 0), (0, 0), (4, 4), (4, 4)))
+    ref = np.concatenate([O.conv2d(fp[b:b + 1, :, y:y + 15, x:x + 15], _q(w, "f16"), None, 1, 1, 1)
+                          for b, (y, x) in enumerate(pos)])
+    for tile in WREG_TILES:
+        y = ops.conv2d(torch.from_numpy(f).cuda(), w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4, dtype="f16",
+                       algo="wreg", tile=tile)
+        assert rel_err(y.cpu().numpy(), ref) <= TOL["f16"], tile
+    g = _rand(rng, 2, 32, 15, 15)
+    w2 = _rand(rng, 16, 32, 3, 3) / 17
+    ref2 = O.conv2d(O.upsample_nearest(_q(g, "f16"), (31, 31)), _q(w2, "f16"), None, 1, 1, 1)
+    for tile in ((64, 64), (128, 64)):
+        y = ops.conv2d(torch.from_numpy(g).cuda(), w2, pad=1, ups=(31, 31), dtype="f16", algo="wreg", tile=tile)
+        assert rel_err(y.cpu().numpy(), ref2) <= TOL["f16"], tile
