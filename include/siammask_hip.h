@@ -136,6 +136,12 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
              float *cls_out, float *loc_out, float *mask_out, double *box_out, float *refine_out,
              void *stream);
 
+/* persistent per-XCD convolution sequences (fp16, batch >= 8: the ResNet stages run as conv_seq_kernel launches, one
+ * workgroup per CU, image b on XCD b % 8).  grid_out = workgroups per launch (0: the placement check at smk_create
+ * failed and the per-layer kernels are used); err_out = device flag (0 ok, 1 placement violated, 2 barrier timeout).
+ * Synchronises the device.  Returns non-zero when err != 0. */
+int smk_seq_status(smk_ctx *ctx, int *grid_out, int *err_out);
+
 /* capture the launch sequences into hipGraphs and replay them (on by default when the
  * environment variable SMK_GRAPH is not "0"); graphs are keyed on (entry, batch, flags,
  * I/O pointers), so keep the I/O buffers stable to hit the cache. */

@@ -24,7 +24,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 # every symbol include/siammask_hip.h declares
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
-    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode",
+    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status",
     "smk_debug_read", "smk_tune", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",

@@ -16,7 +16,12 @@
 //   wave tile  = (32*FM) x 64;  workgroup tile = (32*FM) x (64*WN);  WK > 1 splits the k-steps of a K tile
 //   K tile     = 128 B (64 halves), NSTAGE-deep A ring, ONE s_barrier per K tile (same protocol as conv_igemm_kernel)
 // f16 only, NHWC epilogue only (the callers fall back to conv_igemm_kernel otherwise).
+//
+// conv_seq_kernel (below) runs a whole SEQUENCE of such convolutions as ONE persistent launch: one workgroup per CU,
+// the 32 workgroups of an XCD form a team that owns the images b = xcd, xcd + 8, ... and walks the layer list
+// with team-local barriers; activations handed from layer to layer never leave the XCD's L2.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "smk_kernels.h"
 
 namespace smk {
@@ -29,15 +34,35 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int A, int B> struct WMax { static constexpr int v = A > B ? A : B; };
 
-template <int FM, int WN, int WK, int NSTAGE>
-__global__ __launch_bounds__(384, (WMax<NSTAGE * 32 * FM * 128, 4 * 32 * FM * 68 * 4>::v <= 80 * 1024 ? 2 : 1))
-void conv_wreg_kernel(const ConvBatch cb) {
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < CONV_BATCH_MAX; ++i)
-        if (i < cb.n && (int)blockIdx.x >= cb.start[i]) pi = i;
-    const ConvParams &p = cb.p[pi];
-    const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
+// per output row (b, oy, ox) of any parameter block with the ConvParams field names
+template <class P> __device__ __forceinline__ RowInfo row_info_t(const P &p, int m) {
+    RowInfo r;
+    const int hw = p.Ho * p.Wo;
+    r.b = m / hw;
+    const int rem = m - r.b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    r.ly0 = oy * p.stride - p.pad;
+    r.lx0 = ox * p.stride_x - p.pad;
+    r.oy_org = p.org_y;
+    r.ox_org = p.org_x;
+    if (p.pos) {
+        r.oy_org += p.pos[2 * r.b + 0] * p.pos_mul + p.pos_add;
+        r.ox_org += p.pos[2 * r.b + 1] * p.pos_mul + p.pos_add;
+    }
+    return r;
+}
+
+template <int FM, int NSTAGE> struct WregLds {
+    static constexpr int v = WMax<NSTAGE * 32 * FM * 128, 4 * 32 * FM * 68 * 4>::v;
+};
+
+// ONE output tile rows [m0, min(m0 + BM, m_end)) x channels [n0, n0 + BN) of group g.  Called by all 384 threads of the
+// workgroup; starts and ends with the LDS free.  AUX = cache policy of the ACTIVATION loads (A rows, residual): 0 in
+// the one-conv-per-launch kernel, sc1 (16: served by the L2, never by this CU's L1) in the persistent sequence kernel,
+// where those bytes were written by another CU of the same XCD a moment ago.
+template <int FM, int WN, int WK, int NSTAGE, int AUX, class P>
+__device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
+                                          unsigned char *smem) {
     typedef _Float16 T;
     constexpr int NCW = 4, NPW = 2, NT = (NCW + NPW) * 64;
     static_assert(WN * WK == NCW, "four consumer waves");
@@ -50,25 +75,11 @@ void conv_wreg_kernel(const ConvBatch cb) {
     constexpr int AHEAD = NSTAGE - 1;
     constexpr int STAGE_BYTES = BM * KT;
     constexpr int LDE = 68;
-    constexpr int EPI_BYTES = NCW * BM * LDE * 4;
-    constexpr int LDS_BYTES = WMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.z;
     const int cout_off = p.cout_off + g * p.g_cout_off;
     const float *bias = p.bias + g * p.g_wgt_off;
-
-    const int tilesN = (p.Nst + BN - 1) / BN;
-    int t = (int)blockIdx.x - wg_first;
-    if (p.xcd_mode != 0) {                        // XCD-contiguous tm-major order (see conv_igemm_kernel)
-        const int nblk = wg_count, q = nblk >> 3, r = nblk & 7;
-        const int x = t & 7, j = t >> 3;
-        t = x * q + (x < r ? x : r) + j;
-    }
-    const int tm = t / tilesN, tn = t - tm * tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int nk = p.Kpad / BK;                   // K tiles (Kpad is a multiple of 128 elements: nk is even)
 
     floatx16 acc[FM][2];
@@ -84,8 +95,8 @@ void conv_wreg_kernel(const ConvBatch cb) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = m0 + lrow + RPR * i;
-            rvalid[i] = m < p.M;
-            ri[i] = row_info(p, rvalid[i] ? m : 0, p.pos);
+            rvalid[i] = m < m_end;
+            ri[i] = row_info_t(p, rvalid[i] ? m : m0);
         }
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
         constexpr long OOB = 0x7ffff000;
@@ -136,7 +147,7 @@ void conv_wreg_kernel(const ConvBatch cb) {
 #pragma unroll
             for (int j = 0; j < RA; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(sA + j * (RPR * KT)), 16,
-                                                         (int)(a_off[j] + cbyte), 0, 0, 0);
+                                                         (int)(a_off[j] + cbyte), 0, 0, AUX);
         };
 #pragma unroll
         for (int tt = 0; tt < AHEAD; ++tt)
@@ -257,11 +268,15 @@ void conv_wreg_kernel(const ConvBatch cb) {
 #pragma unroll
         for (int q = 0; q < EV; ++q) rv[ps][q] = (_Float16)0.f;
     if (p.res_mode != RES_NONE && ncol_ok) {
-        const T *res = (const T *)p.res;
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int row = ps * RPP + r0, m = m0 + row;
-            if (row < BM && m < p.M) rv[ps] = *(const half8 *)(res + (size_t)m * p.res_Cs + p.res_coff + n);
+            if (row < BM && m < m_end) {
+                const uint4v x = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_res, (int)(((size_t)m * p.res_Cs + p.res_coff + n) * sizeof(T)), 0, AUX);
+                rv[ps] = __builtin_bit_cast(half8, x);
+            }
         }
     }
     if (wave < NCW) {
@@ -278,38 +293,142 @@ void conv_wreg_kernel(const ConvBatch cb) {
                 }
     }
     __syncthreads();
-    if (!ncol_ok) return;
-    const float *ecol = (const float *)smem + ((c4 >> 6) * WK) * (BM * LDE) + (c4 & 63);
-    float bv[EV];
+    if (ncol_ok) {
+        const float *ecol = (const float *)smem + ((c4 >> 6) * WK) * (BM * LDE) + (c4 & 63);
+        float bv[EV];
 #pragma unroll
-    for (int q = 0; q < EV; q += 4) {
-        const floatx4 b4 = *(const floatx4 *)(bias + n + q);
-        bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
-    }
-    T *out = (T *)p.out;
+        for (int q = 0; q < EV; q += 4) {
+            const floatx4 b4 = *(const floatx4 *)(bias + n + q);
+            bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
+        }
+        T *out = (T *)p.out;
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int row = ps * RPP + r0, m = m0 + row;
-        if (row < BM && m < p.M) {
-            const float *er = ecol + row * LDE;
-            half8 o;
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int row = ps * RPP + r0, m = m0 + row;
+            if (row < BM && m < m_end) {
+                const float *er = ecol + row * LDE;
+                half8 o;
 #pragma unroll
-            for (int q = 0; q < EV; q += 4) {
-                floatx4 x = *(const floatx4 *)(er + q);
+                for (int q = 0; q < EV; q += 4) {
+                    floatx4 x = *(const floatx4 *)(er + q);
 #pragma unroll
-                for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (BM * LDE) + q);
+                    for (int kq = 1; kq < WK; ++kq) x += *(const floatx4 *)(er + kq * (BM * LDE) + q);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float v = x[u] + bv[q + u];
-                    if (p.res_mode == RES_PRE_RELU) v += (float)rv[ps][q + u];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.res_mode == RES_POST_RELU) v += (float)rv[ps][q + u];
-                    o[q + u] = (_Float16)v;
+                    for (int u = 0; u < 4; ++u) {
+                        float v = x[u] + bv[q + u];
+                        if (p.res_mode == RES_PRE_RELU) v += (float)rv[ps][q + u];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.res_mode == RES_POST_RELU) v += (float)rv[ps][q + u];
+                        o[q + u] = (_Float16)v;
+                    }
                 }
+                *(half8 *)(out + (size_t)m * p.Cos + cout_off + n) = o;
             }
-            *(half8 *)(out + (size_t)m * p.Cos + cout_off + n) = o;
         }
     }
+    __syncthreads();                                     // the LDS is free again (the next tile's producers may start)
+}
+
+// ---- one convolution (or a merged batch of independent ones) per launch ------------------------------------------
+template <int FM, int WN, int WK, int NSTAGE>
+__global__ __launch_bounds__(384, (WregLds<FM, NSTAGE>::v <= 80 * 1024 ? 2 : 1))
+void conv_wreg_kernel(const ConvBatch cb) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CONV_BATCH_MAX; ++i)
+        if (i < cb.n && (int)blockIdx.x >= cb.start[i]) pi = i;
+    const ConvParams &p = cb.p[pi];
+    const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
+    constexpr int BM = 32 * FM, BN = 64 * WN;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<FM, NSTAGE>::v];
+    const int tilesN = (p.Nst + BN - 1) / BN;
+    int t = (int)blockIdx.x - wg_first;
+    if (p.xcd_mode != 0) {                        // XCD-contiguous tm-major order (see conv_igemm_kernel)
+        const int nblk = wg_count, q = nblk >> 3, r = nblk & 7;
+        const int x = t & 7, j = t >> 3;
+        t = x * q + (x < r ? x : r) + j;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    wreg_tile<FM, WN, WK, NSTAGE, 0>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_seq_kernel: a sequence of convolutions (a ResNet stage: Bottleneck after Bottleneck) as ONE persistent launch.
+//
+// Why: at B = 8 the step is ~50 dependent launches of 7-20 us.  Every launch boundary costs 1.5-2 us plus the
+// write-back of what the predecessor left dirty (B / 6 TB/s), the grid fill / drain and each workgroup's cold start,
+// and the next layer re-reads its input from the fabric because it was produced under other XCDs' L2s.  MI355X is
+// eight XCDs with a private 4 MB L2 each -- and the workload is B independent images.  So: image b belongs to XCD
+// b % 8 for the WHOLE sequence.  The 32 workgroups of an XCD (one per CU; block i runs on XCD i % 8, checked against
+// HW_REG_XCC_ID) share the tiles of their images layer by layer; between dependent layers they meet at a TEAM-LOCAL
+// barrier: plain stores (they stay in the XCD's L2) -> s_waitcnt vmcnt(0) -> one L2-executed atomic per workgroup ->
+// sc1 polls.  No agent-scope release / acquire, no L2 write-back, no L1 invalidate: the consumers read the handed-over
+// activations with sc1 loads (L2-served), and a layer's 2 MB of activations are L2 hits for the next one.
+// Weights are read-only (plain loads).  The kernel boundary at the end publishes the results to everybody else.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void team_barrier(unsigned *cnt, unsigned target, int *err) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's stores have reached the L2
+    __syncthreads();                                                   // ... and every wave's of this workgroup
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // executes in the XCD's L2
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // sc1 load: L2-served
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 20000000ull) {                   // 0.2 s at 100 MHz: never hang the GPU
+                atomicExch(err, 2);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<2, 3>::v];
+    const int team = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((int)(xcc & 0xf) != team && threadIdx.x == 0) atomicExch(a.err, 1);     // placement assumption broken: reported
+    }
+    unsigned *cnt = a.bar + team * 32;                   // one 128-byte line per team
+    unsigned nbar = 0;
+    for (int li = 0; li < a.n; ++li) {
+        const SeqLayer &L = a.L[li];
+        const int bn = L.cfg == 0 ? 256 : (L.cfg == 1 ? 128 : 64);
+        const int tilesN = (L.Nst + bn - 1) / bn;
+        const int hw = L.Ho * L.Wo;
+        const int tiles = ((hw + 63) >> 6) * tilesN;
+        for (int img = team; img < a.B; img += 8)
+            for (int t = slot; t < tiles; t += nslots) {
+                const int tm = t / tilesN, tn = t - tm * tilesN;
+                const int m0 = img * hw + tm * 64, m_end = (img + 1) * hw;
+                if (L.cfg == 0) wreg_tile<2, 4, 1, 3, 16>(L, 0, m0, m_end, tn * 256, smem);
+                else if (L.cfg == 1) wreg_tile<2, 2, 2, 3, 16>(L, 0, m0, m_end, tn * 128, smem);
+                else wreg_tile<2, 1, 4, 3, 16>(L, 0, m0, m_end, tn * 64, smem);
+            }
+        if (L.sync && li + 1 < a.n) {
+            ++nbar;
+            team_barrier(cnt, nbar * (unsigned)nslots, a.err);
+        }
+    }
+    // the counters return to zero for the next launch: the LAST workgroup of the team to leave resets them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (prev == (unsigned)nslots - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// census: which XCD does block i run on?  (smk_create checks the i % 8 assumption once per context)
+__global__ void xcc_census_kernel(int *out) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(xcc & 0xf);
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
@@ -352,6 +471,21 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
         if (bn == 64) return launch_wreg_t<4, 1, 4>(cb, stages, s);
     }
     return 1;
+}
+
+int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
+    if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
+    hipLaunchKernelGGL(conv_seq_kernel, dim3(grid), dim3(384), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int xcc_census(int grid, int *out_host) {
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(int) * grid) != hipSuccess) return -4;
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(grid), dim3(384), 0, 0, d);
+    hipError_t e = hipMemcpy(out_host, d, sizeof(int) * grid, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? 0 : -4;
 }
 
 }  // namespace smk

@@ -210,6 +210,14 @@ struct smk_ctx {
     void *dec_scratch = nullptr;     // decode: per-stream winners of the A workgroups + arrival counters
     float *ks_part = nullptr;        // split-K: f32 partial tiles (KS_PART_FLOATS) and per-tile arrival counters
     unsigned *ks_cnt = nullptr;
+    // persistent per-XCD convolution sequences (conv_seq_kernel)
+    unsigned *seq_bar = nullptr;     // [8][32] u32 team counters, zero between launches
+    int *seq_err = nullptr;          // device flag written by the kernel (placement / barrier timeout)
+    int seq_grid = 0;                // workgroups of a sequence launch (= CUs) when the placement check passed, else 0
+    bool seq_on = false;             // run_conv records into seq_rec instead of launching
+    std::vector<SeqLayer> seq_rec;
+    std::vector<std::string> seq_ids;
+    double seq_flop = 0.0, seq_bytes = 0.0;
 
     // decode (tools/test.py:205-254 on device)
     float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
@@ -500,6 +508,10 @@ static int build_arena(smk_ctx *c) {
     HIPCHK(hipMemset(c->pos_dev, 0, sizeof(int) * 2 * c->maxB));
     HIPCHK(hipMalloc((void **)&c->ks_part, KS_PART_FLOATS * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->ks_cnt, KS_CNT * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void **)&c->seq_bar, 8 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->seq_bar, 0, 8 * 32 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void **)&c->seq_err, sizeof(int)));
+    HIPCHK(hipMemset(c->seq_err, 0, sizeof(int)));
     HIPCHK(hipMemset(c->ks_cnt, 0, KS_CNT * sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->dec_scratch, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
     HIPCHK(hipMemset(c->dec_scratch, 0, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
@@ -650,6 +662,56 @@ static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt 
     return tiles128 >= 300 ? 128 : 64;
 }
 
+// ---- persistent per-XCD convolution sequences (conv_seq_kernel) ---------------------------------------------------
+// While c->seq_on, run_conv / run_conv_jobs RECORD eligible convolutions instead of launching them; seq_flush turns the
+// recorded list into persistent launches of <= SEQ_MAX layers.  Everything else (non-eligible convolutions, other
+// kernels) flushes first, so program order is preserved.
+static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
+    if (!conv_wreg_eligible(p, dtype) || p.groups > 1 || p.pos || p.ups || p.Kpad % 128) return false;
+    if (p.kh > 15 || p.kw > 15 || p.stride > 15 || p.pad > 15 || p.dil > 15) return false;
+    memset(&L, 0, sizeof(L));
+    L.in = p.in; L.wgt_frag = p.wgt_frag; L.bias = p.bias; L.res = p.res; L.out = p.out;
+    L.in_bytes = p.in_bytes; L.w_bytes = p.w_bytes;
+    L.Hs = p.Hs; L.Ws = p.Ws; L.Cs = p.Cs; L.cin_off = p.cin_off; L.Ci = p.Ci; L.Hl = p.Hl; L.Wl = p.Wl;
+    L.org_y = p.org_y; L.org_x = p.org_x; L.Ho = p.Ho; L.Wo = p.Wo;
+    L.Kpad = p.Kpad; L.Nst = p.Nst; L.Cos = p.Cos; L.cout_off = p.cout_off; L.res_Cs = p.res_Cs; L.res_coff = p.res_coff;
+    L.kw_magic = p.kw_magic;
+    L.kh = (signed char)p.kh; L.kw = (signed char)p.kw; L.stride = (signed char)p.stride; L.stride_x = (signed char)p.stride_x;
+    L.pad = (signed char)p.pad; L.dil = (signed char)p.dil; L.relu = (signed char)p.relu; L.res_mode = (signed char)p.res_mode;
+    L.ci_shift = (signed char)p.ci_shift;
+    // workgroup tile: the widest that still gives the 32 workgroups of an XCD a tile each per image
+    L.cfg = p.Nst >= 512 ? 0 : (p.Nst >= 192 ? 1 : 2);
+    L.sync = 1;
+    return true;
+}
+
+static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
+    const size_t n = c->seq_rec.size();
+    for (size_t i0 = 0; i0 < n; i0 += SEQ_MAX) {
+        SeqArgs a;
+        memset(&a, 0, sizeof(a));
+        a.n = (int)(n - i0 < (size_t)SEQ_MAX ? n - i0 : SEQ_MAX);
+        a.B = B;
+        a.bar = c->seq_bar;
+        a.err = c->seq_err;
+        for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
+        char idn[96];
+        snprintf(idn, sizeof(idn), "seq[%s..%s]", c->seq_ids[i0].c_str(), c->seq_ids[i0 + a.n - 1].c_str());
+        const double fr = (double)a.n / (double)n;
+        ProfScope ps(c, s, idn, "conv_seq", c->seq_flop * fr, c->seq_bytes * fr);
+        if (launch_conv_seq(a, c->seq_grid, s))
+            return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
+    }
+    c->seq_rec.clear();
+    c->seq_ids.clear();
+    c->seq_flop = c->seq_bytes = 0.0;
+    return 0;
+}
+
+static bool seq_wanted(const smk_ctx *c, int B) {
+    return g_tune.seq && c->seq_grid > 0 && c->dtype == DT_F16 && B >= g_tune.seq_min_batch;
+}
+
 // conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
 // (64x256, 64x128, 64x64, 128x256, 128x128, 128x64) or 0.
 static const int WREG_TILE[7][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}};
@@ -677,6 +739,17 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     const double in_bytes = (double)B * (p.ups ? p.Hs * p.Ws : (double)p.Hl * p.Wl) * p.Ci * es * ng;
     const double out_bytes = (double)p.M * p.N * ng * (p.out_mode == OUT_NCHW_F32 ? 4 : es);
     const double bytes = in_bytes + out_bytes + (double)p.N * kreal * es * ng + (p.res ? (double)p.M * p.N * es : 0.0);
+    if (c->seq_on) {
+        SeqLayer L;
+        if (!o.algo_naive && !o.halo && !o.wreg && !o.tile_code && seq_layer_from(p, c->dtype, L)) {
+            c->seq_rec.push_back(L);
+            c->seq_ids.push_back(id);
+            c->seq_flop += flop;
+            c->seq_bytes += bytes;
+            return 0;
+        }
+        CHK(seq_flush(c, B, s));               // not eligible: keep program order
+    }
     char kn[64];
     snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
@@ -720,6 +793,14 @@ struct ConvJob { const char *id; const Act *in; const Act *out; ConvOpt o; };
 
 static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, int lead, hipStream_t s) {
     if (jobs.empty() || (int)jobs.size() > CONV_BATCH_MAX) return fail(SMK_E_ARG, "internal: bad conv job count");
+    if (c->seq_on) {
+        // independent members: no team barrier between them, one after the last
+        const size_t n0 = c->seq_rec.size();
+        for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
+        if (c->seq_rec.size() == n0 + jobs.size())
+            for (size_t i = n0; i + 1 < c->seq_rec.size(); ++i) c->seq_rec[i].sync = 0;
+        return 0;
+    }
     ConvBatch cb;
     cb.n = (int)jobs.size();
     // merging pays while the single problems under-fill the chip; once every halo-eligible member is a full
@@ -782,6 +863,12 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
 
     Act cur = x1;
     int sp = s1;                              // current spatial size
+    // B >= 8, fp16: the three ResNet stages + adjust run as persistent per-XCD sequences (image b on XCD b % 8)
+    struct SeqScope {
+        smk_ctx *c;
+        SeqScope(smk_ctx *c_, bool on) : c(c_) { c->seq_on = on; }
+        ~SeqScope() { c->seq_on = false; c->seq_rec.clear(); c->seq_ids.clear(); c->seq_flop = c->seq_bytes = 0.0; }
+    } seq_scope(c, seq_wanted(c, B) && !parallel_ok(c));
     for (int st = 0; st < 3; ++st) {
         const int planes = STAGE_PLANES[st];
         for (int b = 0; b < STAGE_BLOCKS[st]; ++b) {
@@ -840,6 +927,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
         Act se = act(c, "search", sp, sp, 256);
         CHK(run_conv(c, "adjust", cur, &se, B, oa, s));
     }
+    if (c->seq_on) CHK(seq_flush(c, B, s));
     c->last_B = B; c->last_S = S;
     return 0;
 }
@@ -1098,6 +1186,18 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     int rc = build_arena(c.get());
     if (rc) return rc;
     if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
+    {
+        // conv_seq_kernel assumes block i of a one-block-per-CU launch runs on XCD i % 8 (observed dispatch order, not a
+        // HIP guarantee): check it once per context; if it does not hold the per-launch kernels are used instead
+        const int ncu = prop.multiProcessorCount;
+        c->seq_grid = 0;
+        if (ncu >= 8 && ncu % 8 == 0 && ncu <= 1024) {
+            std::vector<int> x(ncu, -1);
+            bool ok = xcc_census(ncu, x.data()) == 0;
+            for (int i = 0; ok && i < ncu; ++i) ok = x[i] == (i & 7);
+            if (ok) c->seq_grid = ncu;
+        }
+    }
     for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
     c->ev_pool.resize(64);
     for (auto &e : c->ev_pool) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1126,6 +1226,8 @@ int smk_destroy(smk_ctx *c) {
     if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->ks_part) hipFree(c->ks_part);
     if (c->ks_cnt) hipFree(c->ks_cnt);
+    if (c->seq_bar) hipFree(c->seq_bar);
+    if (c->seq_err) hipFree(c->seq_err);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
@@ -1283,6 +1385,19 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     return 0;
 }
 
+int smk_seq_status(smk_ctx *c, int *grid, int *err) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, c->seq_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (grid) *grid = c->seq_grid;
+    if (err) *err = e;
+    if (e) return fail(SMK_E_STATE, "conv_seq_kernel reported %s", e == 1 ? "a workgroup outside its XCD (block i not on XCD i % 8)"
+                                                                         : "a team-barrier timeout");
+    return 0;
+}
+
 int smk_set_graph_mode(smk_ctx *c, int enable) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
     c->graph_mode = enable != 0;
@@ -1350,6 +1465,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
+    else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
+    else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;

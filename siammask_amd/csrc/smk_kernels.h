@@ -77,6 +77,34 @@ struct ConvBatch {
     ConvParams p[CONV_BATCH_MAX];
 };
 
+// one layer of a persistent convolution sequence (conv_seq_kernel): the ConvParams fields conv_wreg's tile routine
+// reads, under the same names, packed so that a whole ResNet stage travels in the 4 KB kernel-argument segment
+struct SeqLayer {
+    const void *in;        // NHWC f16 [B][Hs][Ws][Cs]
+    const void *wgt_frag;  // fragment-order weights
+    const float *bias;
+    const void *res;       // residual (NHWC f16) or nullptr
+    void *out;             // NHWC f16
+    unsigned in_bytes, w_bytes;
+    int Hs, Ws, Cs, cin_off, Ci, Hl, Wl, org_y, org_x, Ho, Wo;
+    int Kpad, Nst, Cos, cout_off, res_Cs, res_coff, kw_magic;
+    signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
+    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64
+    signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
+    signed char pad_[1];
+    // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
+    static constexpr const int *pos = nullptr;
+    static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
+};
+constexpr int SEQ_MAX = 24;
+struct SeqArgs {
+    int n, B;
+    unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits
+    int *err;              // device flag: 1 = block i did not run on XCD i % 8, 2 = barrier timeout
+    SeqLayer L[SEQ_MAX];
+};
+static_assert(sizeof(SeqArgs) <= 4096, "the layer list travels in the kernel-argument segment");
+
 // run-time tuning knobs (smk_tune): measured defaults, overridable for A/B runs
 struct Tuning {
     int xcd_mode = 1;
@@ -101,6 +129,8 @@ struct Tuning {
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
+    int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
+    int seq_min_batch = 8;
 };
 extern Tuning g_tune;
 
@@ -219,6 +249,10 @@ int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);
 // {64,128,256}; returns 1 when a problem of the batch is not eligible
 bool conv_wreg_eligible(const ConvParams &p, int dtype);
 int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stream);
+// a sequence of convolutions as one persistent launch of `grid` workgroups (one per CU, a multiple of 8)
+int launch_conv_seq(const SeqArgs &a, int grid, void *stream);
+// XCD id of every block of a `grid`-block launch -> host array (synchronous; smk_create's placement check)
+int xcc_census(int grid, int *out_host);
 // the sequential tail of Refine (h2, post0, h1, post1, h0, post2) as one launch, fp16 only (refine_chain.hip)
 struct RefineChainLayer {
     const void *w;         // packed weights [rows][Kpad] fp16, K = (tap, channel of a Ci-channel image)

@@ -411,6 +411,14 @@ class Custom(nn.Module):
             self._fast[key] = (args, out)
         return out
 
+    def seq_status(self):
+        """(workgroups per persistent sequence launch or 0, device error flag); raises if the kernel reported an error"""
+        if self._ctx is None:
+            return 0, 0
+        g, e = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().smk_seq_status(self._ctx, ctypes.byref(g), ctypes.byref(e)))
+        return g.value, e.value
+
     # -- per-launch profiling (HIP events around every kernel; bypasses graph replay) -----------
     def profile(self, enable=True):
         if self._ctx is None:
