@@ -60,6 +60,9 @@ template <int FM, int NSTAGE> struct WregLds {
 // workgroup; starts and ends with the LDS free.  AUX = cache policy of the ACTIVATION loads (A rows, residual): 0 in
 // the one-conv-per-launch kernel, sc1 (16: served by the L2, never by this CU's L1) in the persistent sequence kernel,
 // where those bytes were written by another CU of the same XCD a moment ago.
+//
+// (Measured and removed, profiles/r02_wreg_pf_wave.txt: a seventh wave that touched the weight panel's lines 4-32 K tiles
+// ahead of the consumers to warm the XCD's L2 -- no effect on any layer, so the K-tile time is not first-touch L2 latency.)
 template <int FM, int WN, int WK, int NSTAGE, int AUX, class P>
 __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
                                           unsigned char *smem) {
@@ -359,8 +362,8 @@ void conv_wreg_kernel(const ConvBatch cb) {
 // write-back of what the predecessor left dirty (B / 6 TB/s), the grid fill / drain and each workgroup's cold start,
 // and the next layer re-reads its input from the fabric because it was produced under other XCDs' L2s.  MI355X is
 // eight XCDs with a private 4 MB L2 each -- and the workload is B independent images.  So: image b belongs to XCD
-// b % 8 for the WHOLE sequence.  The 32 workgroups of an XCD (one per CU; block i runs on XCD i % 8, checked against
-// HW_REG_XCC_ID) share the tiles of their images layer by layer; between dependent layers they meet at a TEAM-LOCAL
+// b % 8 for the WHOLE sequence.  The 32 workgroups of an XCD (one per CU; a workgroup reads its XCD from
+// HW_REG_XCC_ID and draws a ticket inside the team) share the tiles of their images layer by layer; between dependent layers they meet at a TEAM-LOCAL
 // barrier: plain stores (they stay in the XCD's L2) -> s_waitcnt vmcnt(0) -> one L2-executed atomic per workgroup ->
 // sc1 polls.  No agent-scope release / acquire, no L2 write-back, no L1 invalidate: the consumers read the handed-over
 // activations with sc1 loads (L2-served), and a layer's 2 MB of activations are L2 hits for the next one.
@@ -385,14 +388,26 @@ __device__ __forceinline__ void team_barrier(unsigned *cnt, unsigned target, int
 
 __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<2, 3>::v];
-    const int team = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if ((int)(xcc & 0xf) != team && threadIdx.x == 0) atomicExch(a.err, 1);     // placement assumption broken: reported
+    // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
+    // over the XCDs, starting wherever the previous launch stopped, so blockIdx says nothing); slot = arrival ticket
+    // inside the team.  A one-block-per-CU launch puts gridDim/8 workgroups on every XCD (checked at smk_create).
+    const int nslots = gridDim.x >> 3;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int team = (int)(xcc & 7);
+    unsigned *cnt = a.bar + team * 32;                   // one 128-byte line per team: [0] barrier, [1] exits, [2] tickets
+    int *slot_sh = (int *)smem;
+    if (threadIdx.x == 0) *slot_sh = (int)__hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const int slot = *slot_sh;
+    __syncthreads();
+    if (slot >= nslots) {                                // more workgroups on this XCD than the census promised
+        if (threadIdx.x == 0) atomicExch(a.err, 1);
+        return;
     }
-    unsigned *cnt = a.bar + team * 32;                   // one 128-byte line per team
     unsigned nbar = 0;
+    const bool clk = a.clk && team == 0 && slot == 0 && threadIdx.x == 0;
+    if (clk) a.clk[0] = wall_clock64();
     for (int li = 0; li < a.n; ++li) {
         const SeqLayer &L = a.L[li];
         const int bn = L.cfg == 0 ? 256 : (L.cfg == 1 ? 128 : 64);
@@ -407,10 +422,12 @@ __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
                 else if (L.cfg == 1) wreg_tile<2, 2, 2, 3, 16>(L, 0, m0, m_end, tn * 128, smem);
                 else wreg_tile<2, 1, 4, 3, 16>(L, 0, m0, m_end, tn * 64, smem);
             }
+        if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (L.sync && li + 1 < a.n) {
             ++nbar;
             team_barrier(cnt, nbar * (unsigned)nslots, a.err);
         }
+        if (clk) a.clk[2 + 2 * li] = wall_clock64();
     }
     // the counters return to zero for the next launch: the LAST workgroup of the team to leave resets them
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -420,6 +437,7 @@ __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
         if (prev == (unsigned)nslots - 1) {
             __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }

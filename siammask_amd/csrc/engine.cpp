@@ -695,12 +695,25 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.bar = c->seq_bar;
         a.err = c->seq_err;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
+        static unsigned long long *clk_dev = nullptr;
+        const bool want_clk = getenv("SMK_SEQ_CLK") != nullptr && !c->graph_mode;
+        if (want_clk && !clk_dev) HIPCHK(hipMalloc((void **)&clk_dev, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
+        a.clk = want_clk ? clk_dev : nullptr;
         char idn[96];
         snprintf(idn, sizeof(idn), "seq[%s..%s]", c->seq_ids[i0].c_str(), c->seq_ids[i0 + a.n - 1].c_str());
         const double fr = (double)a.n / (double)n;
         ProfScope ps(c, s, idn, "conv_seq", c->seq_flop * fr, c->seq_bytes * fr);
         if (launch_conv_seq(a, c->seq_grid, s))
             return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
+        if (want_clk) {                                  // measurement aid: per-layer spans of (team 0, slot 0), eager mode only
+            unsigned long long h[2 * SEQ_MAX + 1];
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[seq clk] %s total %.2f us\n", idn, (h[2 * a.n] - h[0]) / 100.0);
+            for (int i = 0; i < a.n; ++i)
+                fprintf(stderr, "[seq clk]   %-10s cfg %d sync %d  tiles %.2f us  barrier %.2f us\n", c->seq_ids[i0 + i].c_str(),
+                        a.L[i].cfg, a.L[i].sync, (h[1 + 2 * i] - h[2 * i]) / 100.0, (h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
+        }
     }
     c->seq_rec.clear();
     c->seq_ids.clear();
@@ -709,7 +722,10 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
 }
 
 static bool seq_wanted(const smk_ctx *c, int B) {
-    return g_tune.seq && c->seq_grid > 0 && c->dtype == DT_F16 && B >= g_tune.seq_min_batch;
+    // measured (tools/measure/gpu_seq_ab.py, profiles/r02_seq_ab.txt): B = 8 (one image per XCD) x1.03-1.04 on the whole
+    // step; B = 16 x0.85, B = 64 x0.79 (two / eight images per team in sequence on 64-row tiles lose to the
+    // chip-wide 128/256-row tiles) -> on for one image per XCD only
+    return g_tune.seq && c->seq_grid > 0 && c->dtype == DT_F16 && B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch;
 }
 
 // conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
@@ -720,7 +736,19 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (o.wreg) return o.wreg;
     if (g_tune.wreg >= 2) return g_tune.wreg - 1;
     if (!g_tune.wreg) return 0;
-    return 0;                                  // per-shape choice: fitted below once measured
+    // per-shape choice, fitted to profiles/r02_wregbench_b8_b64.json (A/B against the best LDS-staged instantiation in
+    // one process): the register path wins where the weight stream is long and the tile is N-wide -- the two strided /
+    // wide 3x3 projections (l2.0.ds x1.10-1.15, l3.0.ds x1.05-1.08) and, while M is small (B <= ~16), the 1x1
+    // reductions with K >= 512 (l3.c1 x1.13, l3.0.c1 x1.10, l2.c1 x1.07) and the strided 3x3 of l2.0 (x1.06).
+    // It loses on layer1 (short K, large M: x0.5-0.9) and against the halo kernel on 3x3 stride-1 layers.
+    const long K = (long)p.kh * p.kw * p.Ci;
+    if (p.M < 4096) return 0;                  // not measured below B ~ 5: keep the fitted LDS-staged choice
+    if (p.kh == 3 && K >= 2304 && p.Nst >= 512)
+        return ((long)((p.M + 127) / 128) * ((p.Nst + 255) / 256) >= 200) ? 4 : 1;       // 128x256 once it fills the chip
+    if (p.M > 16384) return 0;
+    if (p.kh == 1 && K >= 512 && p.Nst <= 256) return p.Nst >= 192 ? 2 : 3;               // 64x128 / 64x64
+    if (p.kh == 3 && p.stride == 2 && K >= 1152 && p.Nst <= 128) return 3;
+    return 0;
 }
 static int wreg_stages() { return g_tune.wreg_stages ? g_tune.wreg_stages : 3; }
 
@@ -1187,15 +1215,25 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     if (rc) return rc;
     if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
     {
-        // conv_seq_kernel assumes block i of a one-block-per-CU launch runs on XCD i % 8 (observed dispatch order, not a
-        // HIP guarantee): check it once per context; if it does not hold the per-launch kernels are used instead
+        // conv_seq_kernel assumes that a one-block-per-CU launch puts the same number of blocks on every XCD (the
+        // dispatcher deals consecutive blocks round-robin over the XCDs -- observed, not a HIP guarantee): check it once
+        // per context; if it does not hold the per-launch kernels are used instead
         const int ncu = prop.multiProcessorCount;
         c->seq_grid = 0;
         if (ncu >= 8 && ncu % 8 == 0 && ncu <= 1024) {
             std::vector<int> x(ncu, -1);
-            bool ok = xcc_census(ncu, x.data()) == 0;
-            for (int i = 0; ok && i < ncu; ++i) ok = x[i] == (i & 7);
+            const int crc = xcc_census(ncu, x.data());
+            bool ok = crc == 0;
+            int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; ok && i < ncu; ++i) {
+                if (x[i] < 0 || x[i] > 7) ok = false;
+                else per[x[i]]++;
+            }
+            for (int q = 0; ok && q < 8; ++q) ok = per[q] == ncu / 8;
             if (ok) c->seq_grid = ncu;
+            else if (getenv("SMK_DEBUG"))
+                fprintf(stderr, "[siammask_hip] XCD placement check failed (rc %d, %d CUs, per XCD %d %d %d %d %d %d %d %d): "
+                        "persistent sequences off\n", crc, ncu, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7]);
         }
     }
     for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -1393,7 +1431,7 @@ int smk_seq_status(smk_ctx *c, int *grid, int *err) {
     HIPCHK(hipMemcpy(&e, c->seq_err, sizeof(int), hipMemcpyDeviceToHost));
     if (grid) *grid = c->seq_grid;
     if (err) *err = e;
-    if (e) return fail(SMK_E_STATE, "conv_seq_kernel reported %s", e == 1 ? "a workgroup outside its XCD (block i not on XCD i % 8)"
+    if (e) return fail(SMK_E_STATE, "conv_seq_kernel reported %s", e == 1 ? "an uneven distribution of workgroups over the XCDs"
                                                                          : "a team-barrier timeout");
     return 0;
 }
@@ -1467,6 +1505,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
+    else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
     else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;

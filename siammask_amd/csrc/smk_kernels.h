@@ -99,8 +99,10 @@ struct SeqLayer {
 constexpr int SEQ_MAX = 24;
 struct SeqArgs {
     int n, B;
-    unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits
-    int *err;              // device flag: 1 = block i did not run on XCD i % 8, 2 = barrier timeout
+    unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits, [2] tickets
+    int *err;              // device flag: 1 = an XCD received more workgroups than grid / 8, 2 = barrier timeout
+    unsigned long long *clk;   // optional [2 * SEQ_MAX + 1]: 100 MHz timestamps of (team 0, slot 0): start, then per layer
+                               //   (tiles done, barrier passed) -- measurement aid (SMK_SEQ_CLK=1)
     SeqLayer L[SEQ_MAX];
 };
 static_assert(sizeof(SeqArgs) <= 4096, "the layer list travels in the kernel-argument segment");
@@ -130,7 +132,7 @@ struct Tuning {
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
     int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
-    int seq_min_batch = 8;
+    int seq_min_batch = 8, seq_max_batch = 8;
 };
 extern Tuning g_tune;
 

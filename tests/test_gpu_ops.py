@@ -314,7 +314,7 @@ def test_conv_wreg_windows_and_upsample():
         assert rel_err(y.cpu().numpy(), ref) <= TOL["f16"], tile
     g = _rand(rng, 2, 32, 15, 15)
     w2 = _rand(rng, 16, 32, 3, 3) / 17
-    ref2 = O.conv2d(O.upsample_nearest(_q(g, "f16"), (31, 31)), _q(w2, "f16"), None, 1, 1, 1)
+    ref2 = O.conv2d(O.upsample_nearest(_q(g, "f16"), 31), _q(w2, "f16"), None, 1, 1, 1)
     for tile in ((64, 64), (128, 64)):
         y = ops.conv2d(torch.from_numpy(g).cuda(), w2, pad=1, ups=(31, 31), dtype="f16", algo="wreg", tile=tile)
         assert rel_err(y.cpu().numpy(), ref2) <= TOL["f16"], tile
