@@ -15,8 +15,9 @@ scaling, no data-path collective) and gathers boxes/masks with one RCCL all_gath
 of the K frames, inside the timed region.
 
 Prints ONE JSON line (driver contract) with two extra objects:
-  roofline     -- dominant kernel family (the MFMA implicit-GEMM convolutions: conv_igemm_kernel and
-                  its 3x3 patch-sharing sibling conv3x3_halo_kernel): algorithmic FLOPs of its
+  roofline     -- dominant kernel family (the MFMA implicit-GEMM convolutions: conv_igemm_kernel, its 3x3
+                  patch-sharing sibling conv3x3_halo_kernel, the register-fed conv_wreg_kernel and the persistent
+                  per-XCD conv_seq_kernel that runs whole ResNet stages at B = 8): algorithmic FLOPs of its
                   launches / their HIP-event durations, measured live on the launch stream by the
                   library's per-launch profiler (smk_profile);
   cpu_baseline -- the CPU port of the reference op sequence (oracle/torch_port.py) timed on
@@ -218,7 +219,8 @@ def timed_run(w, steps, warmup, world, gather, res=None):
     return dt
 
 
-CONV_FAMILY = "conv_igemm+conv3x3_halo"
+CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg+conv_seq"
+CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg", "conv_seq")
 
 
 def roofline(w, steps=3):
@@ -233,7 +235,7 @@ def roofline(w, steps=3):
     fam = {}
     for r in recs:
         k = r["kernel"].split("<")[0]
-        k = CONV_FAMILY if k in ("conv_igemm", "conv3x3_halo") else k     # the two MFMA implicit-GEMM conv kernels
+        k = CONV_FAMILY if k in CONV_KERNELS else k     # the MFMA implicit-GEMM conv kernels (LDS-staged, register-fed, persistent)
         f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0})
         f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["bytes"] += r["bytes"]; f["calls"] += r["calls"]
     total_ms = sum(f["ms"] for f in fam.values())
@@ -241,7 +243,7 @@ def roofline(w, steps=3):
     d = fam[dom]
     peak = PEAK_TFLOPS[w.dtype]
     achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    heavy = max((r for r in recs if r["kernel"].startswith(("conv_igemm", "conv3x3_halo"))), key=lambda r: r["ms"])
+    heavy = max((r for r in recs if r["kernel"].startswith(CONV_KERNELS)), key=lambda r: r["ms"])
     xc = fam.get("dw_xcorr")
     out = {
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -424,6 +426,12 @@ def main():
     frames = w.B * world * args.steps
     fps = frames / dt
 
+    seq = None
+    if not args.stub:
+        # persistent per-XCD sequences: workgroups per launch (0 = per-layer kernels) and the device error flag; an error
+        # (uneven XCD placement, barrier timeout) means the timed results are not trustworthy -> no line
+        g_, e_ = w.model.seq_status()
+        seq = {"workgroups": g_, "err": e_}
     roof, recs = None, []
     if not args.stub:
         try:
@@ -474,6 +482,7 @@ def main():
                        "name": w.name, "variant": w.variant, "batch_per_gpu": w.B,
                        "global_batch": w.B * world, "parallelism": "streams sharded x%d" % world,
                        "weights": "synthetic_damped (calibrated random init)", "graph": True,
+                       "persistent_sequences": seq,
                        "step": ("track_mask -> device decode -> track_refine, one graph" if w.fused
                                 else "track_mask ; track_refine(fixed pos)"),
                        "gflop_per_frame": w.gflop_per_frame()},

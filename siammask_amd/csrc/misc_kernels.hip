@@ -309,10 +309,12 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream) {
 constexpr int DEC_THREADS = 640;                 // >= S*S = 625 candidates of one anchor shape
 __device__ __forceinline__ float exp_f32_cr(float x) { return (float)exp((double)x); }
 
-__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams p) {
-    const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S;
-    const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
-    const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
+// one candidate per thread: `have` = this thread owns candidate rem of anchor shape a; c0, c1 = the two class logits,
+// l0..l3 = the four box regressions of that candidate (float32, as the network returned them)
+__device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, const int b, const int rem, const bool have,
+                                            const float c0, const float c1, const float l0, const float l1, const float l2,
+                                            const float l3) {
+    const int SS = p.S * p.S;
     // target_sz_in_crop (float64, :230) and the two float64 scalars derived from it
     const double tw = p.target_wh[2 * b], th = p.target_wh[2 * b + 1];
     const double tpad = __dmul_rn(__dadd_rn(tw, th), 0.5);
@@ -323,19 +325,17 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     double best = -1e300;
     int best_i = 0x7fffffff;
     double box[6] = {0., 0., 0., 0., 0., 0.};
-    const int rem = threadIdx.x;
-    if (rem < SS) {
+    if (have) {
         // float32 stage
-        const float c0 = cls[a * SS + rem], c1 = cls[(p.A + a) * SS + rem];
         const float m = fmaxf(c0, c1);
         const float e0 = exp_f32_cr(__fsub_rn(c0, m)), e1 = exp_f32_cr(__fsub_rn(c1, m));
         const float score = __fdiv_rn(e1, __fadd_rn(e0, e1));                     // softmax(...)[:, 1]
         const float aw = p.anchor_w[a], ah = p.anchor_h[a];
         const int y = rem / p.S, x = rem - y * p.S;
-        const float cx = __fadd_rn(__fmul_rn(loc[(0 * p.A + a) * SS + rem], aw), (float)(ori + p.stride * x));
-        const float cy = __fadd_rn(__fmul_rn(loc[(1 * p.A + a) * SS + rem], ah), (float)(ori + p.stride * y));
-        const float w = __fmul_rn(exp_f32_cr(loc[(2 * p.A + a) * SS + rem]), aw);
-        const float h = __fmul_rn(exp_f32_cr(loc[(3 * p.A + a) * SS + rem]), ah);
+        const float cx = __fadd_rn(__fmul_rn(l0, aw), (float)(ori + p.stride * x));
+        const float cy = __fadd_rn(__fmul_rn(l1, ah), (float)(ori + p.stride * y));
+        const float w = __fmul_rn(exp_f32_cr(l2), aw);
+        const float h = __fmul_rn(exp_f32_cr(l3), ah);
         const float pad = __fmul_rn(__fadd_rn(w, h), 0.5f);
         const float sz = __fsqrt_rn(__fmul_rn(__fadd_rn(w, pad), __fadd_rn(h, pad)));
         const float ratio = __fdiv_rn(w, h);
@@ -402,6 +402,88 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
             o[q] = __longlong_as_double((long long)__hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+__global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams p) {
+    const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S;
+    const float *cls = p.cls + (size_t)b * 2 * p.A * SS;
+    const float *loc = p.loc + (size_t)b * 4 * p.A * SS;
+    const int rem = threadIdx.x;
+    const bool have = rem < SS;
+    float c0 = 0.f, c1 = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    if (have) {
+        c0 = cls[a * SS + rem]; c1 = cls[(p.A + a) * SS + rem];
+        l0 = loc[(0 * p.A + a) * SS + rem]; l1 = loc[(1 * p.A + a) * SS + rem];
+        l2 = loc[(2 * p.A + a) * SS + rem]; l3 = loc[(3 * p.A + a) * SS + rem];
+    }
+    decode_tail(p, a, b, rem, have, c0, c1, l0, l1, l2, l3);
+}
+
+// ------------------------------------------------------------------------------------------
+// heads_decode_kernel<T>: the two small head convolutions cls.head.3 / loc.head.3 (1x1, 256 -> 10 / 20, + bias;
+// models/rpn.py:56-61,71) AND the decode above in ONE launch (fused frame step only).  As separate launches they
+// were ~10 us (one merged MFMA launch for 0.17 GFLOP per stream) + ~11 us of decode, both launch-floor bound.
+// Workgroup (a, b) needs exactly six output channels -- class logits {a, A + a}, box regressions {a, A+a, 2A+a, 3A+a}
+// -- at the 625 positions: one thread per position, fp32 FMA chains over the 256 input channels of the cls / loc
+// thirds of head.0's output (NHWC, 16-byte loads), the six weight rows in LDS (broadcast reads).  The logits are
+// written to the NCHW f32 tensors the caller gets (same values the convolution launch would hand back, up to fp32
+// summation order) and go on to the decode in registers.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void heads_decode_kernel(const HeadsDecodeParams hp) {
+    const DecodeParams &p = hp.dec;
+    const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S, A = p.A;
+    constexpr int VE = 16 / (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) float wl[6][256 + 4];
+    __shared__ float bl[6];
+    // stage the six weight rows (K = 256 input channels) as fp32
+    for (int i = threadIdx.x; i < 6 * 256; i += DEC_THREADS) {
+        const int r = i >> 8, k = i & 255;
+        const T *w = r < 2 ? (const T *)hp.w_cls + (size_t)(r * A + a) * hp.kpad_cls
+                           : (const T *)hp.w_loc + (size_t)((r - 2) * A + a) * hp.kpad_loc;
+        wl[r][k] = (float)w[k];
+    }
+    if (threadIdx.x < 6)
+        bl[threadIdx.x] = threadIdx.x < 2 ? hp.b_cls[threadIdx.x * A + a] : hp.b_loc[(threadIdx.x - 2) * A + a];
+    __syncthreads();
+    const int rem = threadIdx.x;
+    const bool have = rem < SS;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (have) {
+        const T *xc = (const T *)hp.h0 + ((size_t)b * SS + rem) * hp.cs + hp.cls_off;
+        const T *xl = (const T *)hp.h0 + ((size_t)b * SS + rem) * hp.cs + hp.loc_off;
+        typedef T vec_t __attribute__((ext_vector_type(VE)));
+#pragma unroll 4
+        for (int k = 0; k < 256; k += VE) {
+            const vec_t vc = *(const vec_t *)(xc + k), vl = *(const vec_t *)(xl + k);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float fc = (float)vc[e], fl = (float)vl[e];
+                acc[0] = fmaf(fc, wl[0][k + e], acc[0]);
+                acc[1] = fmaf(fc, wl[1][k + e], acc[1]);
+                acc[2] = fmaf(fl, wl[2][k + e], acc[2]);
+                acc[3] = fmaf(fl, wl[3][k + e], acc[3]);
+                acc[4] = fmaf(fl, wl[4][k + e], acc[4]);
+                acc[5] = fmaf(fl, wl[5][k + e], acc[5]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[r] += bl[r];
+        float *cls = hp.cls_out + (size_t)b * 2 * A * SS, *loc = hp.loc_out + (size_t)b * 4 * A * SS;
+        cls[a * SS + rem] = acc[0]; cls[(A + a) * SS + rem] = acc[1];
+        loc[(0 * A + a) * SS + rem] = acc[2]; loc[(1 * A + a) * SS + rem] = acc[3];
+        loc[(2 * A + a) * SS + rem] = acc[4]; loc[(3 * A + a) * SS + rem] = acc[5];
+    }
+    decode_tail(p, a, b, rem, have, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+}
+
+int launch_heads_decode(const HeadsDecodeParams &hp, int dtype, void *stream) {
+    const DecodeParams &p = hp.dec;
+    if (p.A > 8 || p.B < 1 || p.S * p.S > DEC_THREADS || !p.part_val || !p.part_idx || !p.part_box || !p.arrived) return -1;
+    if (dtype == DT_F16) hipLaunchKernelGGL(heads_decode_kernel<_Float16>, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, hp);
+    else hipLaunchKernelGGL(heads_decode_kernel<float>, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, hp);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 int launch_decode(const DecodeParams &p, void *stream) {

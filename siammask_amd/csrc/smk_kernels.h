@@ -127,6 +127,8 @@ struct Tuning {
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
+    int heads_decode = 1;      // fused frame step: cls3 + loc3 + decode as one launch (heads_decode_kernel)
+    int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
@@ -217,6 +219,17 @@ struct DecodeParams {
     double penalty_k, window_influence;
 };
 
+// cls.head.3 + loc.head.3 + decode in one launch (heads_decode_kernel)
+struct HeadsDecodeParams {
+    DecodeParams dec;        // cls / loc inside are unused (the logits come from registers)
+    const void *h0;          // head.0 output NHWC [B][S*S][cs] (dtype); cls third at cls_off, loc third at loc_off
+    int cs, cls_off, loc_off;
+    const void *w_cls, *w_loc;     // packed [rows][kpad] (dtype), rows = 2A / 4A
+    int kpad_cls, kpad_loc;
+    const float *b_cls, *b_loc;
+    float *cls_out, *loc_out;      // NCHW f32 [B][2A][S][S], [B][4A][S][S]
+};
+
 // image ops either side of the network (image_kernels.hip); per-stream scalars travel in the kernarg
 constexpr int CROP_MAX_B = 32;
 struct CropParams {
@@ -276,6 +289,7 @@ int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
+int launch_heads_decode(const HeadsDecodeParams &hp, int dtype, void *stream);
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);
 int launch_paste_labels(const PasteParams &p, int n_obj, void *stream);
