@@ -74,7 +74,8 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
     constexpr int RPR = NPW * 64 / 8;            // rows filled by one round of producer pieces (16)
     constexpr int RA = BM / RPR;                 // pieces per producer lane per K tile
     constexpr int NKS = 4 / WK;                  // k-steps (16 halves of K) per K tile per consumer
-    constexpr int D = 2 * NKS;                   // weight fragments are loaded two K tiles ahead
+    constexpr int D = 2 * NKS;                   // weight fragments are loaded two K tiles ahead (four ahead + a 6-deep A ring
+                                                 // measured 0-15 % slower on every layer: profiles/r02_wreg_deep_ring.txt)
     constexpr int AHEAD = NSTAGE - 1;
     constexpr int STAGE_BYTES = BM * KT;
     constexpr int LDE = 68;

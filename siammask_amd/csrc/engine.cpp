@@ -606,7 +606,8 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     // line aligned, offset), so the first / last line of every segment is completed by the NEIGHBOURING M tile.  tn-major
     // order runs the M neighbours of one channel block back to back on one XCD: the partial lines meet in that L2
     // before they are evicted (tm-major: the neighbour comes tilesN tiles later -> read-modify-write at the memory side)
-    if (o.nchw_out && g_tune.nchw_tn_major && p.xcd_mode == 1 && (double)p.M * p.N * 4 >= 4.0e6) p.xcd_mode = 2;
+    // (measured, profiles/r02_tail_ab.txt: B=64 -1.3 % on the step, B=8 / B=1 within noise -> large launches only)
+    if (o.nchw_out && g_tune.nchw_tn_major && p.xcd_mode == 1 && p.M >= 20000 && (double)p.M * p.N * 4 >= 4.0e6) p.xcd_mode = 2;
     p.prio = g_tune.prio;
     {
         const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
@@ -901,8 +902,12 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
         smk_ctx *c;
         SeqScope(smk_ctx *c_, bool on) : c(c_) { c->seq_on = on; }
         ~SeqScope() { c->seq_on = false; c->seq_rec.clear(); c->seq_ids.clear(); c->seq_flop = c->seq_bytes = 0.0; }
-    } seq_scope(c, seq_wanted(c, B) && !parallel_ok(c));
+    } seq_scope(c, false);
+    const bool seq_ok = seq_wanted(c, B) && !parallel_ok(c);
     for (int st = 0; st < 3; ++st) {
+        // layer1 stays on the per-launch kernels: short K and 63 tiles of 64 rows per image (two rounds for 32 workgroups)
+        // made it 140 us inside the sequence against 96 us as launches (SMK_SEQ_CLK, profiles/r02_seq_ab.txt)
+        if (seq_ok && st == g_tune.seq_first_stage) c->seq_on = true;
         const int planes = STAGE_PLANES[st];
         for (int b = 0; b < STAGE_BLOCKS[st]; ++b) {
             char idb[32];
@@ -975,17 +980,11 @@ static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
     return 0;
 }
 
-struct DecodeFuse { const double *target_wh; int *pos_out; double *box_out; bool done; };
-static void fill_decode_params(smk_ctx *c, const float *cls, const float *loc, int B, const double *target_wh, int *pos_out,
-                               double *box_out, DecodeParams &p);
-
 // defer_mask_join: the 63x63 mask head (HBM-write bound, nothing on the device reads it) is forked
 // to a side stream and only joined by the caller at the end of the frame step, so that it runs
 // beside the small decode / Refine launches instead of in front of them
-// df != nullptr (fused frame step): cls.head.3 + loc.head.3 + the decode run as ONE launch (heads_decode_kernel);
-// df->done tells the caller whether that happened
 static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
-                     hipStream_t s, bool defer_mask_join = false, DecodeFuse *df = nullptr) {
+                     hipStream_t s, bool defer_mask_join = false) {
     CHK(run_backbone(c, x, B, 255, s));
     const int nbt = nbranch(c);                                   // branches laid out in the buffers
     const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
@@ -1011,21 +1010,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
     ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
-    if (df) df->done = false;
-    if (df && g_tune.heads_decode && !par && c->conv.count("cls3") && c->conv.count("loc3")) {
-        const PackedConv &pc = c->conv.at("cls3"), &pl = c->conv.at("loc3");
-        HeadsDecodeParams hp;
-        memset(&hp, 0, sizeof(hp));
-        fill_decode_params(c, cls, loc, B, df->target_wh, df->pos_out, df->box_out, hp.dec);
-        hp.h0 = h0.p; hp.cs = h0.C; hp.cls_off = 0; hp.loc_off = 256;
-        hp.w_cls = pc.w; hp.w_loc = pl.w; hp.kpad_cls = pc.Kpad; hp.kpad_loc = pl.Kpad;
-        hp.b_cls = pc.bias; hp.b_loc = pl.bias;
-        hp.cls_out = cls; hp.loc_out = loc;
-        const double hflop = 2.0 * B * 625.0 * 256.0 * 30.0;
-        ProfScope ps(c, s, "cls3+loc3+decode", "heads_decode", hflop, (double)B * 625 * (512.0 * esize(c->dtype) + 30 * 4));
-        if (launch_heads_decode(hp, c->dtype, s)) return fail(SMK_E_HIP, "heads_decode launch failed");
-        df->done = true;
-    } else if (par) {
+    if (par) {
         CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
         CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
     } else {
@@ -1528,9 +1513,9 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
-    else if (!strcmp(key, "heads_decode")) g_tune.heads_decode = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
+    else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
     else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
@@ -1660,9 +1645,8 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     GraphKey key{3, B, flags, {x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) {
-        DecodeFuse df{target_wh, c->pos_dev, box_out, false};
-        CHK(seq_track(c, x, B, flags, cls, loc, mask, st, true, &df));
-        if (!df.done) CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
+        CHK(seq_track(c, x, B, flags, cls, loc, mask, st, true));
+        CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
         if (refine_out) CHK(seq_refine(c, B, refine_out, st));
         if (c->mask_join_pending) {
             c->mask_join_pending = false;

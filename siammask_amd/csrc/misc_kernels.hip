@@ -420,72 +420,6 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     decode_tail(p, a, b, rem, have, c0, c1, l0, l1, l2, l3);
 }
 
-// ------------------------------------------------------------------------------------------
-// heads_decode_kernel<T>: the two small head convolutions cls.head.3 / loc.head.3 (1x1, 256 -> 10 / 20, + bias;
-// models/rpn.py:56-61,71) AND the decode above in ONE launch (fused frame step only).  As separate launches they
-// were ~10 us (one merged MFMA launch for 0.17 GFLOP per stream) + ~11 us of decode, both launch-floor bound.
-// Workgroup (a, b) needs exactly six output channels -- class logits {a, A + a}, box regressions {a, A+a, 2A+a, 3A+a}
-// -- at the 625 positions: one thread per position, fp32 FMA chains over the 256 input channels of the cls / loc
-// thirds of head.0's output (NHWC, 16-byte loads), the six weight rows in LDS (broadcast reads).  The logits are
-// written to the NCHW f32 tensors the caller gets (same values the convolution launch would hand back, up to fp32
-// summation order) and go on to the decode in registers.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(DEC_THREADS) void heads_decode_kernel(const HeadsDecodeParams hp) {
-    const DecodeParams &p = hp.dec;
-    const int a = blockIdx.x, b = blockIdx.y, SS = p.S * p.S, A = p.A;
-    constexpr int VE = 16 / (int)sizeof(T);
-    __shared__ __attribute__((aligned(16))) float wl[6][256 + 4];
-    __shared__ float bl[6];
-    // stage the six weight rows (K = 256 input channels) as fp32
-    for (int i = threadIdx.x; i < 6 * 256; i += DEC_THREADS) {
-        const int r = i >> 8, k = i & 255;
-        const T *w = r < 2 ? (const T *)hp.w_cls + (size_t)(r * A + a) * hp.kpad_cls
-                           : (const T *)hp.w_loc + (size_t)((r - 2) * A + a) * hp.kpad_loc;
-        wl[r][k] = (float)w[k];
-    }
-    if (threadIdx.x < 6)
-        bl[threadIdx.x] = threadIdx.x < 2 ? hp.b_cls[threadIdx.x * A + a] : hp.b_loc[(threadIdx.x - 2) * A + a];
-    __syncthreads();
-    const int rem = threadIdx.x;
-    const bool have = rem < SS;
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (have) {
-        const T *xc = (const T *)hp.h0 + ((size_t)b * SS + rem) * hp.cs + hp.cls_off;
-        const T *xl = (const T *)hp.h0 + ((size_t)b * SS + rem) * hp.cs + hp.loc_off;
-        typedef T vec_t __attribute__((ext_vector_type(VE)));
-#pragma unroll 4
-        for (int k = 0; k < 256; k += VE) {
-            const vec_t vc = *(const vec_t *)(xc + k), vl = *(const vec_t *)(xl + k);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                const float fc = (float)vc[e], fl = (float)vl[e];
-                acc[0] = fmaf(fc, wl[0][k + e], acc[0]);
-                acc[1] = fmaf(fc, wl[1][k + e], acc[1]);
-                acc[2] = fmaf(fl, wl[2][k + e], acc[2]);
-                acc[3] = fmaf(fl, wl[3][k + e], acc[3]);
-                acc[4] = fmaf(fl, wl[4][k + e], acc[4]);
-                acc[5] = fmaf(fl, wl[5][k + e], acc[5]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[r] += bl[r];
-        float *cls = hp.cls_out + (size_t)b * 2 * A * SS, *loc = hp.loc_out + (size_t)b * 4 * A * SS;
-        cls[a * SS + rem] = acc[0]; cls[(A + a) * SS + rem] = acc[1];
-        loc[(0 * A + a) * SS + rem] = acc[2]; loc[(1 * A + a) * SS + rem] = acc[3];
-        loc[(2 * A + a) * SS + rem] = acc[4]; loc[(3 * A + a) * SS + rem] = acc[5];
-    }
-    decode_tail(p, a, b, rem, have, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
-}
-
-int launch_heads_decode(const HeadsDecodeParams &hp, int dtype, void *stream) {
-    const DecodeParams &p = hp.dec;
-    if (p.A > 8 || p.B < 1 || p.S * p.S > DEC_THREADS || !p.part_val || !p.part_idx || !p.part_box || !p.arrived) return -1;
-    if (dtype == DT_F16) hipLaunchKernelGGL(heads_decode_kernel<_Float16>, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, hp);
-    else hipLaunchKernelGGL(heads_decode_kernel<float>, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, hp);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
-}
-
 int launch_decode(const DecodeParams &p, void *stream) {
     if (p.A > 8 || p.B < 1 || p.S * p.S > DEC_THREADS || !p.part_val || !p.part_idx || !p.part_box || !p.arrived) return -1;
     hipLaunchKernelGGL(decode_kernel, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, p);

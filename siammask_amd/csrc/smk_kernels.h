@@ -127,7 +127,6 @@ struct Tuning {
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
-    int heads_decode = 1;      // fused frame step: cls3 + loc3 + decode as one launch (heads_decode_kernel)
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
@@ -135,6 +134,7 @@ struct Tuning {
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
     int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
     int seq_min_batch = 8, seq_max_batch = 8;
+    int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
 };
 extern Tuning g_tune;
 
@@ -219,17 +219,6 @@ struct DecodeParams {
     double penalty_k, window_influence;
 };
 
-// cls.head.3 + loc.head.3 + decode in one launch (heads_decode_kernel)
-struct HeadsDecodeParams {
-    DecodeParams dec;        // cls / loc inside are unused (the logits come from registers)
-    const void *h0;          // head.0 output NHWC [B][S*S][cs] (dtype); cls third at cls_off, loc third at loc_off
-    int cs, cls_off, loc_off;
-    const void *w_cls, *w_loc;     // packed [rows][kpad] (dtype), rows = 2A / 4A
-    int kpad_cls, kpad_loc;
-    const float *b_cls, *b_loc;
-    float *cls_out, *loc_out;      // NCHW f32 [B][2A][S][S], [B][4A][S][S]
-};
-
 // image ops either side of the network (image_kernels.hip); per-stream scalars travel in the kernarg
 constexpr int CROP_MAX_B = 32;
 struct CropParams {
@@ -289,7 +278,6 @@ int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
-int launch_heads_decode(const HeadsDecodeParams &hp, int dtype, void *stream);
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);
 int launch_paste_labels(const PasteParams &p, int n_obj, void *stream);

@@ -254,24 +254,9 @@ def test_fused_step_equals_separate_calls(dtype):
     twh = torch.tensor([[60.0, 80.0]] * 2, dtype=torch.float64).cuda()
     out = m.track_step(x, twh)
     torch.cuda.synchronize()
-    # cls / loc of the fused step come from heads_decode_kernel (fp32 FMA chains over the same inputs and weights as the
-    # convolution launch of track_mask: equal up to fp32 summation order); mask and Refine are the same launches
-    for name, a, b in (("cls", out["cls"], cls), ("loc", out["loc"], loc)):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-6, name
-    assert torch.equal(out["mask"], mask)
+    assert torch.equal(out["cls"], cls) and torch.equal(out["loc"], loc) and torch.equal(out["mask"], mask)
     assert [int(v) for v in out["box"][:, 7].cpu()] == [t[0] for t in best]
     assert torch.equal(out["refine"], ref)
-    from siammask_amd import _lib
-    _lib.tune(heads_decode=0)                      # the two-launch form (cls3 + loc3 convolution, then decode): bit-equal
-    try:
-        m2 = _model("sharp", "synthetic_damped", dtype, True)
-        m2.template(z)
-        out2 = m2.track_step(x, twh)
-        torch.cuda.synchronize()
-        assert torch.equal(out2["cls"], cls) and torch.equal(out2["loc"], loc) and torch.equal(out2["refine"], ref)
-        assert torch.equal(out2["box"], out["box"])
-    finally:
-        _lib.tune(heads_decode=1)
     if dtype == "f32":
         assert rel_err(out["refine"].cpu().numpy(), g["refine"]) <= 1e-4
 
