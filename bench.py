@@ -219,8 +219,8 @@ def timed_run(w, steps, warmup, world, gather, res=None):
     return dt
 
 
-CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg+conv_seq"
-CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg", "conv_seq")
+CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg+conv_seq+chain_mask"
+CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg", "conv_seq", "chain_mask")
 
 
 def roofline(w, steps=3):

@@ -142,15 +142,22 @@ template <int STAGE_BYTES, int NSTAGE, int EPI, int NWAVES> struct WgPerCu {
 #define SMK_NCW (WM * WN * WK)
 #define SMK_EPI (SMK_NCW * 64 * 68 * 4)
 
+template <int WM, int WN, int WK, int KT, int NSTAGE> struct IgemmLds {
+    static constexpr int v = CMax<NSTAGE * 64 * (WM + WN) * KT, SMK_EPI>::v;
+};
+
+// the body of conv_igemm_kernel for (virtual) workgroup bx of group bz, run by the (NCW + 4) * 64 threads whose index is
+// threadIdx.x - tid0, in `smem` (IgemmLds<...>::v bytes): a plain kernel calls it with (blockIdx.x, blockIdx.z, 0); the
+// horizontally fused tail kernel (chain_mask_kernel) runs two of them side by side in one 1024-thread workgroup
 template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
-__global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
-void conv_igemm_kernel(const ConvBatch cb) {
+__device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int bx, const int bz, const int tid0,
+                                                unsigned char *smem) {
     // several independent convolutions can share one launch (same instantiation): workgroups
     // [start[i], start[i+1]) belong to problem i
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < CONV_BATCH_MAX; ++i)
-        if (i < cb.n && (int)blockIdx.x >= cb.start[i]) pi = i;
+        if (i < cb.n && bx >= cb.start[i]) pi = i;
     const ConvParams &p = cb.p[pi];
     const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
     constexpr int NCW = SMK_NCW;               // consumer waves (4 or 8); 4 producer waves follow
@@ -171,12 +178,11 @@ void conv_igemm_kernel(const ConvBatch cb) {
     constexpr int STAGE_BYTES = (BM + BN) * KT;
     constexpr int LDE = 68;                    // NHWC: row-major [64 rows][68]; NCHW: column-major [64 cols][68]
     constexpr int EPI_BYTES = NCW * 64 * LDE * 4;               // one 64x64 f32 accumulator tile per consumer
-    constexpr int LDS_BYTES = CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    static_assert(CMax<NSTAGE * STAGE_BYTES, EPI_BYTES>::v == IgemmLds<WM, WN, WK, KT, NSTAGE>::v, "LDS size");
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = (int)threadIdx.x - tid0, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.z;
+    const int g = bz;
     const int cout_off = p.cout_off + g * p.g_cout_off;
     const float *bias = p.bias + g * p.g_wgt_off;
 
@@ -185,7 +191,7 @@ void conv_igemm_kernel(const ConvBatch cb) {
     // tile sequence, so the workgroups sharing one activation row panel (same tm, all tn) run
     // on ONE XCD and that panel is fetched into one L2 only.
     const int tilesN = (p.Nst + BN - 1) / BN;
-    int t = (int)blockIdx.x - wg_first;
+    int t = bx - wg_first;
     if (p.xcd_mode != 0) {
         const int nblk = wg_count, q = nblk >> 3, r = nblk & 7;
         const int x = t & 7, j = t >> 3;
@@ -612,6 +618,13 @@ void conv_igemm_kernel(const ConvBatch cb) {
     }
 }
 
+template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
+__global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
+void conv_igemm_kernel(const ConvBatch cb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IgemmLds<WM, WN, WK, KT, NSTAGE>::v];
+    conv_igemm_body<T, WM, WN, WK, KT, OUT_MODE, NSTAGE>(cb, (int)blockIdx.x, (int)blockIdx.z, 0, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // conv3x3_halo_kernel<T, WM, WN, WK, AROWS, NSLOT, NPATCH> -- 3x3 stride-1 convolutions with the activation patch
 // staged ONCE per channel chunk and shared by all nine taps.
@@ -946,6 +959,47 @@ int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream) {
     }
     if (bm == 128) return launch_halo_t<float, 2, 2, 1, 320, 2, 1>(p, s);
     return db ? launch_halo_t<float, 1, 2, 2, 224, 3, 2>(p, s) : launch_halo_t<float, 1, 2, 2, 224, 3, 1>(p, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain_mask_kernel: Refine's sequential tail and the 63x63 mask head side by side in ONE launch (horizontal fusion).
+// refine_chain_kernel occupies B of the 256 CUs for ~44 us (one workgroup per stream, custom.py:150-153 is a dependent
+// chain); the mask head (256 -> 3969 1x1 convolution, custom.py:185, 79 MB of fp32 logits at B = 8) is bound by its
+// stores and by nothing on the Refine path -- it only needs head.0's output.  As two launches they cost ~44 + ~40 us
+// back to back.  Here workgroups [0, B) run the chain (all 1024 threads) and the others run TWO 128x128 mask-head
+// tiles each (threads 0-511 / 512-1023, an LDS half each: the same two-workgroups-per-CU overlap the stand-alone
+// launch has; both halves execute the same number of barriers).  Cross-stream forks in the captured graph were the
+// measured alternative: hipGraphLaunch then costs ~1 ms of host time per replay.
+// ---------------------------------------------------------------------------------------------
+}  // namespace smk
+namespace smk {
+#include "refine_chain_body.inc"
+constexpr int CM_CONV_LDS = IgemmLds<2, 2, 1, 128, 2>::v;
+constexpr int CM_LDS = CMax<RC_LDS, 2 * CM_CONV_LDS>::v;
+
+__global__ __launch_bounds__(1024) void chain_mask_kernel(const RefineChainParams rp, const ConvBatch cb) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[CM_LDS];
+    if ((int)blockIdx.x < rp.B) {
+        refine_chain_body<false>(rp, (int)blockIdx.x, smem);
+        return;
+    }
+    const int half = threadIdx.x >> 9;
+    const int bx = 2 * ((int)blockIdx.x - rp.B) + half;
+    if (bx >= cb.start[cb.n]) return;                  // odd tile count: the last workgroup runs one tile
+    conv_igemm_body<_Float16, 2, 2, 1, 128, OUT_NCHW_F32, 2>(cb, bx, 0, half * 512, smem + half * CM_CONV_LDS);
+}
+
+// cb: ONE f16 problem with the NCHW f32 epilogue (the mask head), 128x128 tiles
+int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream) {
+    if (rp.v2_cs != 32 || rp.v1_cs != 16 || rp.v0_cs != 8 || cb.n != 1) return -1;
+    ConvParams &p = cb.p[0];
+    if (p.out_mode != OUT_NCHW_F32 || p.groups > 1) return -1;
+    const int tiles = ((p.M + 127) / 128) * ((p.Nst + 127) / 128);
+    cb.start[0] = 0;
+    for (int i = 1; i <= CONV_BATCH_MAX; ++i) cb.start[i] = tiles;
+    p.ksplit = 1;
+    hipLaunchKernelGGL(chain_mask_kernel, dim3(rp.B + (tiles + 1) / 2), dim3(1024), 0, (hipStream_t)stream, rp, cb);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 // ---- naive reference kernel: one thread per (m, 4 channels); same params, same packing ----

@@ -215,6 +215,10 @@ struct smk_ctx {
     int *seq_err = nullptr;          // device flag written by the kernel (placement / barrier timeout)
     int seq_grid = 0;                // workgroups of a sequence launch (= CUs) when the placement check passed, else 0
     bool seq_on = false;             // run_conv records into seq_rec instead of launching
+    // fused frame step: the mask head is handed to the Refine chain launch (chain_mask_kernel) instead of its own launch
+    bool defer_mask_req = false, have_deferred_mask = false;
+    ConvParams deferred_mask;
+    double deferred_mask_flop = 0.0, deferred_mask_bytes = 0.0;
     std::vector<SeqLayer> seq_rec;
     std::vector<std::string> seq_ids;
     double seq_flop = 0.0, seq_bytes = 0.0;
@@ -1018,7 +1022,16 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     }
     if (want_mask) {
         ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
-        if (defer_mask_join && !par && !c->prof && g_tune.mask_overlap && c->side[0]) {
+        if (c->defer_mask_req && !par) {
+            // handed to seq_refine: it runs inside the chain launch, beside the (B-workgroup) Refine chain
+            auto it = c->conv.find("mask3");
+            if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv mask3 not packed");
+            CHK(conv_params(c, it->second, h0, nullptr, B, om, c->deferred_mask));
+            const ConvParams &mp = c->deferred_mask;
+            c->deferred_mask_flop = 2.0 * mp.M * (double)mp.N * mp.kh * mp.kw * mp.Ci;
+            c->deferred_mask_bytes = (double)mp.M * mp.Ci * esize(c->dtype) + (double)mp.M * mp.N * 4 + (double)mp.N * mp.Ci * esize(c->dtype);
+            c->have_deferred_mask = true;
+        } else if (defer_mask_join && !par && !c->prof && g_tune.mask_overlap && c->side[0]) {
             CHK(stream_dep(c, s, c->side[0]));
             CHK(run_conv(c, "mask3", h0, nullptr, B, om, c->side[0]));
             c->mask_join_pending = true;
@@ -1111,8 +1124,17 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
             if (!clk_dev) HIPCHK(hipMalloc((void **)&clk_dev, 32 * sizeof(unsigned long long)));
             rp.clk = clk_dev;
         }
-        ProfScope ps(c, s, "refine_chain", "refine_chain", flop,
-                     B * (2.0 * (7200 + 225 * 32 + 961 * 16 + 3721 * 4) + 4.0 * 16129) + wbytes);
+        const double cbytes = B * (2.0 * (7200 + 225 * 32 + 961 * 16 + 3721 * 4) + 4.0 * 16129) + wbytes;
+        if (c->have_deferred_mask && !rp.clk) {
+            ConvBatch cb;
+            cb.n = 1;
+            cb.p[0] = c->deferred_mask;
+            c->have_deferred_mask = false;
+            ProfScope ps(c, s, "refine_chain+mask3", "chain_mask", flop + c->deferred_mask_flop, cbytes + c->deferred_mask_bytes);
+            if (launch_chain_mask(rp, cb, s)) return fail(SMK_E_HIP, "chain_mask launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return 0;
+        }
+        ProfScope ps(c, s, "refine_chain", "refine_chain", flop, cbytes);
         if (launch_refine_chain(rp, s)) return fail(SMK_E_HIP, "refine_chain launch failed: %s", hipGetErrorString(hipGetLastError()));
         if (rp.clk) {
             unsigned long long hh[22];
@@ -1513,6 +1535,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
+    else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
@@ -1645,9 +1668,21 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     GraphKey key{3, B, flags, {x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) {
-        CHK(seq_track(c, x, B, flags, cls, loc, mask, st, true));
+        // sharp fp16 with Refine: the mask head rides in the Refine chain launch (see chain_mask_kernel)
+        c->have_deferred_mask = false;
+        c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
+                            c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c);
+        int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, true);
+        c->defer_mask_req = false;
+        CHK(rc2);
         CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
         if (refine_out) CHK(seq_refine(c, B, refine_out, st));
+        if (c->have_deferred_mask) {                 // the chain launch did not take it (timing aid on, ...): its own launch
+            c->have_deferred_mask = false;
+            Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
+            ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
+            CHK(run_conv(c, "mask3", h0, nullptr, B, om, st));
+        }
         if (c->mask_join_pending) {
             c->mask_join_pending = false;
             CHK(stream_dep(c, c->side[0], st));

@@ -127,6 +127,7 @@ struct Tuning {
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
+    int chain_mask = 1;        // fused frame step, fp16: the mask head runs inside the Refine chain launch (chain_mask_kernel)
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
@@ -273,6 +274,8 @@ struct RefineChainParams {
     unsigned long long *clk;              // optional [11]: 100 MHz timestamps of workgroup 0 at the layer boundaries
 };
 int launch_refine_chain(const RefineChainParams &p, void *stream);
+// the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch
+int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);

@@ -8,7 +8,7 @@ import sys
 
 src, workload, label = sys.argv[1], sys.argv[2], sys.argv[3]
 d = json.load(open(src))
-CONV = ("conv_igemm_kernel", "conv3x3_halo_kernel")
+CONV = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv_wreg_kernel", "conv_seq_kernel")
 per = {}
 tot = {"launches": 0, "fetch": 0.0, "write": 0.0}
 for k, c in d.items():
