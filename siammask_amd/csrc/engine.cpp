@@ -1671,7 +1671,8 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
         // sharp fp16 with Refine: the mask head rides in the Refine chain launch (see chain_mask_kernel)
         c->have_deferred_mask = false;
         c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
-                            c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c);
+                            c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
+                            B <= 16;      // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
         int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, true);
         c->defer_mask_req = false;
         CHK(rc2);
