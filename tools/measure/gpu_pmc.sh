@@ -8,7 +8,7 @@ i=0
 for SET in "$@"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmc/pass$i
-  timeout 600 rocprofv3 --pmc $SET --kernel-trace -f csv -d $R/gpurun_out/pmc/pass$i -- $CMD > $R/gpurun_out/pmc/pass$i.out 2> $R/gpurun_out/pmc/pass$i.err
+  timeout 150 rocprofv3 --pmc $SET --kernel-trace -f csv -d $R/gpurun_out/pmc/pass$i -- $CMD > $R/gpurun_out/pmc/pass$i.out 2> $R/gpurun_out/pmc/pass$i.err
   echo "pass $i [$SET] exit $?"
 done
 cd $R
