@@ -219,8 +219,9 @@ def timed_run(w, steps, warmup, world, gather, res=None):
     return dt
 
 
-CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg+conv_seq+chain_mask"
-CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg", "conv_seq", "chain_mask")
+CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg"       # one convolution (or a merged batch) per launch
+CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg")
+MFMA_CONV = CONV_KERNELS + ("conv_seq",)                 # + the persistent per-XCD sequence kernel (its own roofline entry)
 
 
 def roofline(w, steps=3):
@@ -235,7 +236,7 @@ def roofline(w, steps=3):
     fam = {}
     for r in recs:
         k = r["kernel"].split("<")[0]
-        k = CONV_FAMILY if k in CONV_KERNELS else k     # the MFMA implicit-GEMM conv kernels (LDS-staged, register-fed, persistent)
+        k = CONV_FAMILY if k in CONV_KERNELS else k     # the per-launch MFMA implicit-GEMM conv kernels as one family
         f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0})
         f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["bytes"] += r["bytes"]; f["calls"] += r["calls"]
     total_ms = sum(f["ms"] for f in fam.values())
@@ -243,7 +244,7 @@ def roofline(w, steps=3):
     d = fam[dom]
     peak = PEAK_TFLOPS[w.dtype]
     achieved = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    heavy = max((r for r in recs if r["kernel"].startswith(CONV_KERNELS)), key=lambda r: r["ms"])
+    heavy = max((r for r in recs if r["kernel"].startswith(MFMA_CONV)), key=lambda r: r["ms"] / max(1, r["calls"]))
     xc = fam.get("dw_xcorr")
     out = {
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -256,14 +257,27 @@ def roofline(w, steps=3):
                             "tflops": round(heavy["flop"] / (heavy["ms"] * 1e-3) / 1e12, 2)},
         "kernel_ms_per_step": round(total_ms / steps, 4),
     }
+    # every MFMA convolution launch together (the dominant kernel above is one of them): algorithmic flops / their time
+    allc = [f for k, f in fam.items() if k == CONV_FAMILY or k == "conv_seq"]
+    if allc:
+        ms, fl = sum(f["ms"] for f in allc), sum(f["flop"] for f in allc)
+        out["all_mfma_conv"] = {"tflops": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                                "launches_per_step": sum(f["calls"] for f in allc) // steps,
+                                "share_of_gpu_time": round(ms / total_ms, 4)}
+    out["launches_per_step_all_kernels"] = sum(f["calls"] for f in fam.values()) // steps
     # HBM bytes per launch from the PMC counters (collected offline by tools/measure/gpu_pmc.sh with rocprofv3
     # --pmc in separate passes and committed under profiles/; cannot be sampled from inside this process)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % w.name)
     if os.path.exists(pmc):
         try:
             t = json.load(open(pmc))
-            out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
-            out["traffic_note"] = "bytes per launch of the conv kernels (conv_igemm, conv3x3_halo); %s; %s" % (t["source"], t["correction"])
+            bk = t.get("by_kernel", {}).get(dom + "_kernel")
+            if bk:
+                out["traffic"] = bk["hbm_bytes_per_launch_corrected"]
+                out["traffic_note"] = "fabric-side bytes per launch of %s (Infinity-Cache hits included); %s; %s" % (dom, t["source"], t["correction"])
+            else:
+                out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
+                out["traffic_note"] = "bytes per launch of the per-launch conv kernels; %s; %s" % (t["source"], t["correction"])
         except Exception:  # noqa: BLE001
             pass
     out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))

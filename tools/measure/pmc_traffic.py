@@ -26,7 +26,20 @@ for k, c in d.items():
                                      (1024.0 * gui["sum"] / max(1, gui["dispatches"]) / 8.0 + 1e-9), 3),
               "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT", {"sum": 0})["sum"]}
     tot["launches"] += n; tot["fetch"] += f; tot["write"] += w
+def one(name):
+    for k, c in d.items():
+        if name in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            nf, nw = c["FETCH_SIZE"]["dispatches"], c["WRITE_SIZE"]["dispatches"]
+            f, w = c["FETCH_SIZE"]["sum"] / nf, c["WRITE_SIZE"]["sum"] / nw
+            hit, req = c.get("TCC_HIT_sum", {"sum": 0, "dispatches": 1}), c.get("TCC_REQ_sum", {"sum": 1, "dispatches": 1})
+            return {"kernel": k, "fetch_kb_per_launch": round(f, 1), "write_kb_per_launch": round(w, 1),
+                    "hbm_bytes_per_launch_corrected": int((2 * f + w) * 1024),
+                    "tcc_hit_rate": round((hit["sum"] / max(1, hit["dispatches"])) / max(1.0, req["sum"] / max(1, req["dispatches"])), 3)}
+    return None
+
+
 out = {"workload": workload,
+       "by_kernel": {n: one(n) for n in ("conv_seq_kernel", "chain_mask_kernel", "dw_xcorr_kernel") if one(n)},
        "source": "%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, tools/measure/gpu_pmc.sh)" % label,
        "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                      "WRITE_SIZE as reported (uncalibrated)",
