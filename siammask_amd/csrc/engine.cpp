@@ -200,6 +200,8 @@ struct smk_ctx {
     bool graph_mode = false;
     hipStream_t cap_stream = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, unsigned long long> graph_used;   // last use (monotonic tick): least-recently-used eviction
+    unsigned long long graph_tick = 0;
 
     // packed convolutions
     std::map<std::string, PackedConv> conv;   // keyed by short layer id
@@ -944,28 +946,6 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
                     CHK(run_conv_jobs(c, {{id_ds.c_str(), &cur, &r, od}, {id_c1.c_str(), &cur, &t1, o1}}, B, 0, s));
                 }
                 res = r;
-            } else if (st == 0 && c->dtype == DT_F16 && g_tune.l1_block && !c->seq_on && !par && cur.C == 256 &&
-                       c->conv.count(id + "c1") && c->conv.count(id + "c2") && c->conv.count(id + "c3")) {
-                // layer1.1 / layer1.2 (identity shortcut, 64 planes at 63x63): the whole Bottleneck as ONE launch with both
-                // 64-plane intermediates in LDS (l1_block.hip): HBM / launch-floor bound as three launches
-                const PackedConv &k1 = c->conv.at(id + "c1"), &k2 = c->conv.at(id + "c2"), &k3 = c->conv.at(id + "c3");
-                const char *oname = (b == STAGE_BLOCKS[st] - 1) ? "p1" : ((b & 1) ? "b" : "a");
-                Act out = act(c, oname, sp, sp, planes * 4);
-                if (k1.Ci == 256 && k1.k == 1 && k2.Ci == 64 && k2.k == 3 && k2.kw == 0 && k3.Ci == 64 && k3.k == 1 && out.p != cur.p) {
-                    L1BlockParams lp;
-                    lp.x = (const _Float16 *)cur.p; lp.out = (_Float16 *)out.p;
-                    lp.w1 = (const _Float16 *)k1.w; lp.w2 = (const _Float16 *)k2.w; lp.w3 = (const _Float16 *)k3.w;
-                    lp.b1 = k1.bias; lp.b2 = k2.bias; lp.b3 = k3.bias;
-                    lp.kp1 = k1.Kpad; lp.kp2 = k2.Kpad; lp.kp3 = k3.Kpad;
-                    lp.B = B; lp.H = sp; lp.W = sp;
-                    const double M = (double)B * sp * sp;
-                    ProfScope ps(c, s, id + "block", "l1_block", 2.0 * M * (256.0 * 64 + 576.0 * 64 + 64.0 * 256),
-                                 2.0 * M * 256 * 2 + 2.0 * (256.0 * 64 + 576.0 * 64 + 64.0 * 256));
-                    if (launch_l1_block(lp, s)) return fail(SMK_E_HIP, "l1_block launch failed: %s", hipGetErrorString(hipGetLastError()));
-                    cur = out;
-                    continue;
-                }
-                CHK(run_conv(c, id_c1.c_str(), cur, &t1, B, o1, s));
             } else {
                 CHK(run_conv(c, id_c1.c_str(), cur, &t1, B, o1, s));
             }
@@ -1228,12 +1208,20 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
         e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e != hipSuccess) return fail(SMK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-        if (c->graphs.size() > 64) {           // bound the cache
-            for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
-            c->graphs.clear();
+        // bound the cache: drop the least recently used graph (a caller that hands over fresh I/O buffers every frame
+        // re-captures every frame anyway -- that is what the staging path is for -- but it must not evict the graphs
+        // of callers with stable buffers)
+        while (c->graphs.size() >= 64) {
+            auto lru = c->graph_used.begin();
+            for (auto u = c->graph_used.begin(); u != c->graph_used.end(); ++u)
+                if (u->second < lru->second) lru = u;
+            auto g = c->graphs.find(lru->first);
+            if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
+            c->graph_used.erase(lru);
         }
         it = c->graphs.emplace(key, ex).first;
     }
+    c->graph_used[key] = ++c->graph_tick;
     HIPCHK(hipGraphLaunch(it->second, s));
     return 0;
 }
@@ -1349,6 +1337,7 @@ int smk_finalize_weights(smk_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+    c->graph_used.clear();
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
     c->conv.clear();
     int rc = build_weights(c);
@@ -1430,6 +1419,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     HIPCHK(hipSetDevice(c->device));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
+    c->graph_used.clear();
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
     c->conv.clear();
     c->finalized = false;
@@ -1557,7 +1547,6 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
-    else if (!strcmp(key, "l1_block")) g_tune.l1_block = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
@@ -1664,6 +1653,7 @@ int smk_set_decode_params(smk_ctx *c, const float *anchor_wh, int n_anchor, int 
     c->window_influence = window_influence;
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);   // hp are baked into captured launches
     c->graphs.clear();
+    c->graph_used.clear();
     return 0;
 }
 

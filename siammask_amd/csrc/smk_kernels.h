@@ -128,7 +128,6 @@ struct Tuning {
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
     int chain_mask = 1;        // fused frame step, fp16: the mask head runs inside the Refine chain launch (chain_mask_kernel)
-    int l1_block = 1;          // fp16: layer1.1 / layer1.2 as one launch each (l1_block_kernel)
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
@@ -277,16 +276,6 @@ struct RefineChainParams {
 int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch
 int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
-// one identity-shortcut Bottleneck with 64 planes on a 256-channel NHWC f16 tensor (layer1.1 / layer1.2) as one launch
-struct L1BlockParams {
-    const _Float16 *x;             // [B][H][W][256] block input (= residual)
-    _Float16 *out;                 // [B][H][W][256]
-    const _Float16 *w1, *w2, *w3;  // packed [rows][Kpad]: conv1 [64][256], conv2 [64][(tap, c) 576 -> kp2], conv3 [256][64 -> kp3]
-    const float *b1, *b2, *b3;     // folded BN shifts
-    int kp1, kp2, kp3;
-    int B, H, W;
-};
-int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);

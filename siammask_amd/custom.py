@@ -370,6 +370,7 @@ class Custom(nn.Module):
             key = (search.data_ptr(), target_wh.data_ptr(), B, bool(refine), bool(mask_head))
             hit = self._fast.get(key) if self._ctx is not None and not self._weights_dirty and not self._hp_dirty else None
             if hit is not None:
+                self._fast[key] = self._fast.pop(key)    # most recently used last
                 args, out = hit
                 _lib.check(self._smk_step(self._ctx, *args, _lib.current_stream_ptr()))
                 return out
@@ -406,8 +407,9 @@ class Custom(nn.Module):
         self._tracked = B if self.variant != "rpn" else 0
         out = {"cls": cls, "loc": loc, "mask": mask, "box": box, "refine": ref}
         if not stage and self._graph:
-            if len(self._fast) > 32:
-                self._fast.clear()
+            self._fast.pop(key, None)
+            while len(self._fast) >= 32:                 # least recently used out (dicts keep insertion order)
+                self._fast.pop(next(iter(self._fast)))
             self._fast[key] = (args, out)
         return out
 

@@ -406,3 +406,25 @@ def test_bench_configuration_b64(dtype, force):
         json.dump(errs, f)
     bad = {k: v for k, v in errs.items() if not v <= tol}
     assert not bad, "B=64 %s force_tile=%d: %s (all %s)" % (dtype, force, bad, errs)
+
+
+def test_graph_cache_lru_keeps_stable_buffers_hot():
+    """serving path (stage=False: graphs keyed on the caller's buffers): a caller that keeps handing over NEW buffers
+    must not evict the graph of a caller with a stable buffer (least-recently-used eviction, engine + Python fast path),
+    and every call stays correct across evictions"""
+    m = _model("sharp", "synthetic_damped", "f16", True)
+    z = torch.from_numpy(synth.smooth_image_batch(1, 127, stream0=9)).cuda()
+    m.template(z)
+    twh = torch.tensor([[60.0, 80.0]], dtype=torch.float64).cuda()
+    stable = torch.from_numpy(synth.smooth_image_batch(1, 255, stream0=9)).cuda()
+    want = {k: v.clone() for k, v in m.track_step(stable, twh, stage=False).items() if v is not None}
+    fresh = [torch.from_numpy(synth.smooth_image_batch(1, 255, stream0=100 + i)).cuda() for i in range(70)]
+    for i, x in enumerate(fresh):                     # 70 > 64 graphs, 70 > 32 fast-path entries
+        m.track_step(x, twh, stage=False)
+        if i % 7 == 0:
+            got = m.track_step(stable, twh, stage=False)
+            assert all(torch.equal(got[k], want[k]) for k in want), i
+    got = m.track_step(stable, twh, stage=False)
+    torch.cuda.synchronize()
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    assert m.seq_status()[1] == 0
