@@ -63,7 +63,7 @@ template <int FM, int NSTAGE> struct WregLds {
 //
 // (Measured and removed, profiles/r02_wreg_pf_wave.txt: a seventh wave that touched the weight panel's lines 4-32 K tiles
 // ahead of the consumers to warm the XCD's L2 -- no effect on any layer, so the K-tile time is not first-touch L2 latency.)
-template <int FM, int WN, int WK, int NSTAGE, int AUX, class P>
+template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, class P = ConvParams>
 __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
                                           unsigned char *smem) {
     typedef _Float16 T;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
     constexpr int RPR = NPW * 64 / 8;            // rows filled by one round of producer pieces (16)
     constexpr int RA = BM / RPR;                 // pieces per producer lane per K tile
     constexpr int NKS = 4 / WK;                  // k-steps (16 halves of K) per K tile per consumer
-    constexpr int D = 2 * NKS;                   // weight fragments are loaded two K tiles ahead (four ahead + a 6-deep A ring
+    constexpr int D = WT * NKS;                  // weight fragments are loaded WT (= 2) K tiles ahead (four ahead + a 6-deep A ring
                                                  // measured 0-15 % slower on every layer: profiles/r02_wreg_deep_ring.txt)
     constexpr int AHEAD = NSTAGE - 1;
     constexpr int STAGE_BYTES = BM * KT;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void team_barrier(unsigned *cnt, unsigned target, int
 }
 
 __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<2, 3>::v];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
     // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
     // over the XCDs, starting wherever the previous launch stopped, so blockIdx says nothing); slot = arrival ticket
     // inside the team.  A one-block-per-CU launch puts gridDim/8 workgroups on every XCD (checked at smk_create).
@@ -411,16 +411,21 @@ __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
     if (clk) a.clk[0] = wall_clock64();
     for (int li = 0; li < a.n; ++li) {
         const SeqLayer &L = a.L[li];
-        const int bn = L.cfg == 0 ? 256 : (L.cfg == 1 ? 128 : 64);
+        const int bn = (L.cfg == 0 || L.cfg == 3) ? 256 : ((L.cfg == 1 || L.cfg == 4) ? 128 : 64);
+        const int bm = L.cfg >= 3 ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
         const int hw = L.Ho * L.Wo;
-        const int tiles = ((hw + 63) >> 6) * tilesN;
+        const int tiles = ((hw + bm - 1) / bm) * tilesN;
         for (int img = team; img < a.B; img += 8)
             for (int t = slot; t < tiles; t += nslots) {
                 const int tm = t / tilesN, tn = t - tm * tilesN;
-                const int m0 = img * hw + tm * 64, m_end = (img + 1) * hw;
+                const int m0 = img * hw + tm * bm, m_end = (img + 1) * hw;
                 if (L.cfg == 0) wreg_tile<2, 4, 1, 3, 16>(L, 0, m0, m_end, tn * 256, smem);
                 else if (L.cfg == 1) wreg_tile<2, 2, 2, 3, 16>(L, 0, m0, m_end, tn * 128, smem);
+                // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
+                // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
+                else if (L.cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1>(L, 0, m0, m_end, tn * 256, smem);
+                else if (L.cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1>(L, 0, m0, m_end, tn * 128, smem);
                 else wreg_tile<2, 1, 4, 3, 16>(L, 0, m0, m_end, tn * 64, smem);
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();

@@ -89,7 +89,7 @@ struct SeqLayer {
     int Hs, Ws, Cs, cin_off, Ci, Hl, Wl, org_y, org_x, Ho, Wo;
     int Kpad, Nst, Cos, cout_off, res_Cs, res_coff, kw_magic;
     signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
-    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64
+    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
     signed char pad_[1];
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
@@ -135,6 +135,7 @@ struct Tuning {
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
     int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
     int seq_min_batch = 8, seq_max_batch = 8;
+    int seq_tall = 1;          // sequences: 128-row tiles for short-K layers that would otherwise need several 64-row rounds
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
 };
 extern Tuning g_tune;
