@@ -1,16 +1,16 @@
 // conv_wreg.hip -- implicit-GEMM convolution with the WEIGHT operand loaded straight into registers.
 //
 // Same contraction as conv_igemm_kernel (C[m][n] = sum_k A[m][k] * W[n][k], BN folded, fused bias / residual / ReLU
-// epilogue; experiments/siammask_sharp/resnet.py:64-103, models/rpn.py:45-60), different data path.  What bounds
-// conv_igemm_kernel (measured in round 1): every consumer wave re-reads BOTH operands of its 64x64
-// tile from LDS -- 4 ds_read_b128 (4 KB) per 4 MFMAs = 32 B per matrix-pipe cycle and wave, 128 B/clk for the four
-// SIMDs of a CU, i.e. the whole LDS bandwidth, and the LDS-DMA of the next tile needs the same LDS ports (consumers
-// alone reach 45 % of the MFMA peak with no loads at all; DMA + consumers 30-36 %).  Here only the ACTIVATION rows go
-// through LDS (they are an im2col gather and are shared by all consumer waves of the workgroup); the weights are
-// packed offline in MFMA-fragment order ("w_frag": one contiguous KB per (32 output channels, 16 k) fragment) and
-// every consumer wave streams its own fragments global -> VGPR with fully coalesced 1 KB buffer loads, two K tiles
-// ahead in a register ring (counted vmcnt by the compiler).  LDS reads per MFMA halve (FM = 2) or quarter per flop
-// (FM = 4: 128 x 64 wave tiles), the LDS-DMA writes drop to the A rows, the weight stream never touches LDS.
+// epilogue; experiments/siammask_sharp/resnet.py:64-103, models/rpn.py:45-60), different data path.  In
+// conv_igemm_kernel every consumer wave re-reads BOTH operands of its 64x64 tile from LDS (4 ds_read_b128 per 4 MFMAs)
+// and both operands are staged by LDS-DMA.  Here only the ACTIVATION rows go through LDS (they are an im2col gather and
+// are shared by all consumer waves of the workgroup); the weights are packed offline in MFMA-fragment order ("w_frag":
+// one contiguous KB per (32 output channels, 16 k) fragment) and every consumer wave streams its own fragments
+// global -> VGPR with fully coalesced 1 KB buffer loads, two K tiles ahead in a register ring (the compiler's counted
+// vmcnt(13..15) waits, checked in the ISA).  LDS reads per MFMA halve (FM = 2) or quarter per flop (FM = 4: 128 x 64
+// wave tiles), the LDS-DMA writes drop to the A rows, the weight stream never touches LDS.
+// Measured (profiles/r02_wregbench_b8_b64.json): +5..15 % on the long-K N-wide layers, slower on short-K large-M layers
+// -- LDS bandwidth (256 B/clk for ds_read_b128 on CDNA4) was NOT what bounded the LDS-staged kernel; DESIGN.md 3.1g.
 //
 //   workgroup  = 4 consumer waves (WN x WK) + 2 producer waves (A rows only, LDS-DMA, XOR swizzle on the source)
 //   wave tile  = (32*FM) x 64;  workgroup tile = (32*FM) x (64*WN);  WK > 1 splits the k-steps of a K tile
