@@ -151,7 +151,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
 #pragma unroll
             for (int j = 0; j < RA; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(sA + j * (RPR * KT)), 16,
-                                                         (int)(a_off[j] + cbyte), 0, 0, AUX);
+                                                         (int)(a_off[j] + cbyte), 0, 0, AUX & 0xff);
         };
 #pragma unroll
         for (int tt = 0; tt < AHEAD; ++tt)
@@ -171,7 +171,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * RA) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + AHEAD < nk) {
+            if (kt + AHEAD < nk && !(AUX & 0x100)) {        // (0x100: measurement build without A refills)
                 set_tile(kt + AHEAD);
                 issue_tile(islot);
             }
@@ -212,8 +212,13 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
         };
         auto mma_part = [&](const half8 (&a)[FM], const half8 (&b)[2], int q0, int q1) {
 #pragma unroll
-            for (int q = q0; q < q1; ++q)
+            for (int q = q0; q < q1; ++q) {
+                if (AUX & 0x400) {                          // (0x400: measurement build without the matrix pipe)
+                    asm volatile("" ::"v"(a[q >> 1]), "v"(b[q & 1]));
+                    continue;
+                }
                 acc[q >> 1][q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[q >> 1], b[q & 1], acc[q >> 1][q & 1], 0, 0, 0);
+            }
         };
         const int S = nk * NKS;                                 // steps of this wave; a multiple of D
 #pragma unroll
@@ -249,7 +254,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
                     mma_part(fa[j & 1], fb[j], FM, 2 * FM);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (decltype(refill)::value) load_w(g0 + j + D, fb[j]);
+                if (decltype(refill)::value && !(AUX & 0x200)) load_w(g0 + j + D, fb[j]);   // (0x200: no W refills)
             }
         };
         int g0 = 0;
@@ -278,7 +283,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
             const int row = ps * RPP + r0, m = m0 + row;
             if (row < BM && m < m_end) {
                 const uint4v x = __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_res, (int)(((size_t)m * p.res_Cs + p.res_coff + n) * sizeof(T)), 0, AUX);
+                    rs_res, (int)(((size_t)m * p.res_Cs + p.res_coff + n) * sizeof(T)), 0, AUX & 0xff);
                 rv[ps] = __builtin_bit_cast(half8, x);
             }
         }
@@ -354,6 +359,19 @@ void conv_wreg_kernel(const ConvBatch cb) {
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
     wreg_tile<FM, WN, WK, NSTAGE, 0>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
+}
+
+// measurement builds (smk_tune "ablate" = 1 no A refills, 2 no W refills, 4 no MFMA; results are wrong by construction)
+template <int FM, int WN, int WK, int ABL>
+__global__ __launch_bounds__(384, (WregLds<FM, 3>::v <= 80 * 1024 ? 2 : 1))
+void conv_wreg_ablate_kernel(const ConvBatch cb) {
+    const ConvParams &p = cb.p[0];
+    constexpr int BM = 32 * FM, BN = 64 * WN;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<FM, 3>::v];
+    const int tilesN = (p.Nst + BN - 1) / BN;
+    const int t = (int)blockIdx.x;
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    wreg_tile<FM, WN, WK, 3, (ABL << 8)>(p, 0, tm * BM, p.M, tn * BN, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -469,6 +487,17 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
     dim3 grid(total, 1, groups);
+    if constexpr ((FM == 2 && WN == 2) || (WN == 4 && WK == 1))      // measurement builds: three tile shapes only
+    if (g_tune.ablate && cb.n == 1 && groups == 1) {
+        switch (g_tune.ablate) {
+        case 1: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 1>), grid, dim3(384), 0, s, cb); break;
+        case 2: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 2>), grid, dim3(384), 0, s, cb); break;
+        case 3: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 3>), grid, dim3(384), 0, s, cb); break;
+        case 4: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 4>), grid, dim3(384), 0, s, cb); break;
+        default: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 7>), grid, dim3(384), 0, s, cb); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4>), grid, dim3(384), 0, s, cb);
     else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3>), grid, dim3(384), 0, s, cb);
     return hipGetLastError() == hipSuccess ? 0 : -4;

@@ -1563,6 +1563,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
+    else if (!strcmp(key, "ablate")) g_tune.ablate = value & 7;
     else if (!strcmp(key, "seq_tall")) g_tune.seq_tall = value != 0;
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }

@@ -135,6 +135,7 @@ struct Tuning {
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
     int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
     int seq_min_batch = 8, seq_max_batch = 8;
+    int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 1;          // sequences: 128-row tiles for short-K layers that would otherwise need several 64-row rounds
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
 };
