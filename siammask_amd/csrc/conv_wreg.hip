@@ -52,8 +52,8 @@ template <class P> __device__ __forceinline__ RowInfo row_info_t(const P &p, int
     return r;
 }
 
-template <int FM, int NSTAGE> struct WregLds {
-    static constexpr int v = WMax<NSTAGE * 32 * FM * 128, 4 * 32 * FM * 68 * 4>::v;
+template <int FM, int NSTAGE, int NCW = 4> struct WregLds {
+    static constexpr int v = WMax<NSTAGE * 32 * FM * 128, NCW * 32 * FM * 68 * 4>::v;
 };
 
 // ONE output tile rows [m0, min(m0 + BM, m_end)) x channels [n0, n0 + BN) of group g.  Called by all 384 threads of the
@@ -67,8 +67,10 @@ template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, class P = Con
 __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
                                           unsigned char *smem) {
     typedef _Float16 T;
-    constexpr int NCW = 4, NPW = 2, NT = (NCW + NPW) * 64;
-    static_assert(WN * WK == NCW, "four consumer waves");
+    constexpr int NCW = WN * WK, NPW = 2, NT = (NCW + NPW) * 64;
+    // (eight consumers -- two MFMA-issuing waves per SIMD in one workgroup, 64x256 as 4x2 and 64x128 as 2x4 -- compile and
+    // pass parity with this routine; measured 0-12 % slower than four on every layer, profiles/r02_wreg_ncw8.txt)
+    static_assert(NCW == 4 && (WK == 1 || WK == 2 || WK == 4), "four consumer waves");
     constexpr int BM = 32 * FM, BN = 64 * WN;
     constexpr int KT = 128, BK = 64, VE = 8;
     constexpr int RPR = NPW * 64 / 8;            // rows filled by one round of producer pieces (16)
@@ -340,7 +342,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
 
 // ---- one convolution (or a merged batch of independent ones) per launch ------------------------------------------
 template <int FM, int WN, int WK, int NSTAGE>
-__global__ __launch_bounds__(384, (WregLds<FM, NSTAGE>::v <= 80 * 1024 ? 2 : 1))
+__global__ __launch_bounds__((WN * WK + 2) * 64, (WregLds<FM, NSTAGE, WN * WK>::v <= 80 * 1024 ? 2 : 1))
 void conv_wreg_kernel(const ConvBatch cb) {
     int pi = 0;
 #pragma unroll
@@ -349,7 +351,7 @@ void conv_wreg_kernel(const ConvBatch cb) {
     const ConvParams &p = cb.p[pi];
     const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
     constexpr int BM = 32 * FM, BN = 64 * WN;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<FM, NSTAGE>::v];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<FM, NSTAGE, WN * WK>::v];
     const int tilesN = (p.Nst + BN - 1) / BN;
     int t = (int)blockIdx.x - wg_first;
     if (p.xcd_mode != 0) {                        // XCD-contiguous tm-major order (see conv_igemm_kernel)
@@ -487,7 +489,7 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
     dim3 grid(total, 1, groups);
-    if constexpr ((FM == 2 && WN == 2) || (WN == 4 && WK == 1))      // measurement builds: three tile shapes only
+    if constexpr ((FM == 2 && WN == 2 && WK == 2) || (WN == 4 && WK == 1))      // measurement builds: three tile shapes only
     if (g_tune.ablate && cb.n == 1 && groups == 1) {
         switch (g_tune.ablate) {
         case 1: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 1>), grid, dim3(384), 0, s, cb); break;
@@ -498,8 +500,8 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4>), grid, dim3(384), 0, s, cb);
-    else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3>), grid, dim3(384), 0, s, cb);
+    if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
+    else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
