@@ -428,3 +428,38 @@ def test_graph_cache_lru_keeps_stable_buffers_hot():
     torch.cuda.synchronize()
     assert all(torch.equal(got[k], want[k]) for k in want)
     assert m.seq_status()[1] == 0
+
+
+def test_persistent_sequences_and_tail_fusion_are_what_runs_at_b8():
+    """Guard against a silent fall-back: on an MI355X the placement check of smk_create passes (256 workgroups per sequence
+    launch), the B = 8 fp16 frame step really is 25 kernel launches (2 conv_seq + chain_mask among them), the device error
+    flag stays 0, and switching both features off changes the outputs only by fp16 summation-order noise."""
+    from siammask_amd import _lib
+    B = 8
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=70)).cuda()
+    x = torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=70)).cuda()
+    twh = torch.tensor([[60.0, 80.0]] * B, dtype=torch.float64).cuda()
+
+    def run(**knobs):
+        _lib.tune(**knobs)
+        m = _model("sharp", "synthetic_damped", "f16", True, max_batch=B)
+        m.template(z)
+        out = {k: v.clone() for k, v in m.track_step(x, twh, refine=True).items() if v is not None}
+        m.profile(True)
+        m.track_step(x, twh, refine=True)
+        recs = m.profile_dump()
+        m.profile(False)
+        torch.cuda.synchronize()
+        return out, recs, m.seq_status()
+
+    try:
+        on, recs, (grid, err) = run(seq=1, chain_mask=1)
+        off, recs_off, _ = run(seq=0, chain_mask=0)
+    finally:
+        _lib.tune(seq=1, chain_mask=1)
+    assert grid == 256 and err == 0
+    kernels = [r["kernel"].split("<")[0] for r in recs]
+    assert kernels.count("conv_seq") == 2 and kernels.count("chain_mask") == 1, kernels
+    assert sum(r["calls"] for r in recs) <= 26 < sum(r["calls"] for r in recs_off), (len(recs), len(recs_off))
+    for k in ("cls", "loc", "mask", "refine"):
+        assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, k
