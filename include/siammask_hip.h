@@ -160,9 +160,13 @@ int smk_set_graph_mode(smk_ctx *ctx, int enable);
  *   "chain" 0|1 (fp16: Refine's nine sequential convolutions as one launch,
  *   refine_chain_kernel; default 1)   "ksplit" 0|1|2|4 (split-K across workgroups with a last-arrival reduction:
  *   off (default; measured a net loss at B=8) | auto for long-K few-tile launches | forced factor).
+ *   "a_stage" 0|1 (conv_wreg_kernel / conv_seq_kernel producers: activation rows by LDS-DMA with the swizzle on the source
+ *   address | global -> VGPR in ascending lane order, swizzle applied by ds_write_b128; same LDS image, bit-identical results).
  * Environment: SMK_CHAIN_CLK=1 makes eager (non-graph) runs print the time workgroup 0 spends in each layer of
  * refine_chain_kernel to stderr (measurement aid). */
 int smk_tune(const char *key, int value);
+/* current value of a knob (tests and A/B scripts restore what they changed; also how a caller reads the defaults) */
+int smk_tune_get(const char *key, int *value);
 
 /* per-launch profiling: with enable != 0 every kernel launch is bracketed by HIP events on the
  * stream it is launched on (graph replay is bypassed while profiling).  smk_profile_dump

@@ -25,7 +25,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
     "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status",
-    "smk_debug_read", "smk_tune", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
+    "smk_debug_read", "smk_tune", "smk_tune_get", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
 )
@@ -82,6 +82,7 @@ def lib():
     L.smk_step.argtypes = [vp, fp, ci, ci, fp, fp, fp, fp, fp, fp, vp]
     L.smk_set_graph_mode.argtypes = [vp, ci]
     L.smk_tune.argtypes = [ctypes.c_char_p, ci]
+    L.smk_tune_get.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci)]
     L.smk_profile.argtypes = [vp, ci]
     L.smk_profile_dump.argtypes = [vp, ctypes.c_char_p, ci]
     ip = ctypes.POINTER(ci)
@@ -125,3 +126,10 @@ def tune(**kw):
     """Set process-wide tuning knobs of the library (A/B measurements)."""
     for k, v in kw.items():
         check(lib().smk_tune(k.encode(), int(v)))
+
+
+def tune_get(key):
+    """Current value of a tuning knob (so that a test can put back what it changed)."""
+    v = ctypes.c_int(0)
+    check(lib().smk_tune_get(key.encode(), ctypes.byref(v)))
+    return v.value

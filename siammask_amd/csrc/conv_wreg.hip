@@ -95,7 +95,11 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
         const int ptid = tid - NCW * 64, pw = wave - NCW;
         const int cin_off = p.cin_off + g * p.g_cin_off;
         const int lrow = ptid >> 3;
-        const int slot = (ptid & 7) ^ ((lrow >> 1) & 7);
+        // LDS-DMA writes lane-linear, so the XOR swizzle of the fragment reads goes on the SOURCE address (the eight lanes of
+        // a row read its 128-byte line in permuted order).  p.a_stage = 1 (smk_tune "a_stage", A/B knob): the lanes read the
+        // line in ascending order into registers and the swizzle is applied by a ds_write_b128 instead (same LDS image).
+        const int wslot = (ptid & 7) ^ ((lrow >> 1) & 7);
+        const int slot = p.a_stage ? (ptid & 7) : wslot;
         RowInfo ri[RA];
         bool rvalid[RA];
 #pragma unroll
@@ -155,6 +159,41 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(sA + j * (RPR * KT)), 16,
                                                          (int)(a_off[j] + cbyte), 0, 0, AUX & 0xff);
         };
+        if (p.a_stage) {
+            // ---- register-staged variant: two K tiles in flight in VGPRs, written to the ring slot of tile kt right before
+            // barrier(kt) (that slot held tile kt - NSTAGE, which nobody reads since barrier(kt - NSTAGE + 1)).  nk is even.
+            uint4v rg[2][RA];
+            auto load_regs = [&](uint4v (&r)[RA]) {
+                const long cbyte = (long)cur_c * (long)sizeof(T);
+#pragma unroll
+                for (int j = 0; j < RA; ++j)
+                    r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(a_off[j] + cbyte), 0, AUX & 0xff);
+            };
+            auto store_regs = [&](const uint4v (&r)[RA], int buf) {
+                unsigned char *sA = smem + buf * STAGE_BYTES + lrow * KT + wslot * 16;
+#pragma unroll
+                for (int j = 0; j < RA; ++j) *(uint4v *)(sA + j * (RPR * KT)) = r[j];
+            };
+            set_tile(0);
+            load_regs(rg[0]);
+            set_tile(1);
+            load_regs(rg[1]);
+            int buf = 0;
+            for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    store_regs(rg[h], buf);                 // the compiler's vmcnt wait covers exactly this tile's loads
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (kt + h + 2 < nk && !(AUX & 0x100)) {
+                        set_tile(kt + h + 2);
+                        load_regs(rg[h]);
+                    }
+                    if (++buf == NSTAGE) buf = 0;
+                }
+            }
+        } else {
 #pragma unroll
         for (int tt = 0; tt < AHEAD; ++tt)
             if (tt < nk) {
@@ -178,6 +217,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
                 issue_tile(islot);
             }
             if (++islot == NSTAGE) islot = 0;
+        }
         }
     } else {
         // =========================== CONSUMER: A fragments from LDS, W fragments from global ======

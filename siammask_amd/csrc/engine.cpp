@@ -618,6 +618,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     {
         const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
         p.buf_lds = (g_tune.buf_lds && ib < 2.0e9 && wb < 2.0e9) ? 1 : 0;
+        p.a_stage = g_tune.a_stage;
         p.in_bytes = (unsigned)(ib < 4.0e9 ? ib : 0);
         p.w_bytes = (unsigned)(wb < 4.0e9 ? wb : 0);
     }
@@ -691,6 +692,7 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     L.kh = (signed char)p.kh; L.kw = (signed char)p.kw; L.stride = (signed char)p.stride; L.stride_x = (signed char)p.stride_x;
     L.pad = (signed char)p.pad; L.dil = (signed char)p.dil; L.relu = (signed char)p.relu; L.res_mode = (signed char)p.res_mode;
     L.ci_shift = (signed char)p.ci_shift;
+    L.a_stage = (signed char)p.a_stage;
     // workgroup tile: the widest that still gives the 32 workgroups of an XCD a tile each per image
     L.cfg = p.Nst >= 512 ? 0 : (p.Nst >= 192 ? 1 : 2);
     // Short-K layers are dominated by the fixed cost of a tile (operand first touch, residual fetch, accumulator hand-over:
@@ -1575,12 +1577,30 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
+    else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
     else return fail(SMK_E_ARG, "smk_tune: unknown key %s", key);
     return 0;
+}
+
+int smk_tune_get(const char *key, int *value) {
+    if (!key || !value) return fail(SMK_E_ARG, "smk_tune_get: null argument");
+    static const struct { const char *name; int *slot; } knobs[] = {
+        {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
+        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
+        {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
+        {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall},
+        {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
+        {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
+        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"mask_overlap", &g_tune.mask_overlap},
+        {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
+    for (const auto &k : knobs)
+        if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
+    return fail(SMK_E_ARG, "smk_tune_get: unknown key %s", key);
 }
 
 int smk_profile(smk_ctx *c, int enable) {

@@ -58,6 +58,7 @@ struct ConvParams {
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
     int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
+    int a_stage;           // conv_wreg / conv_seq producers: 1 = activation rows global -> VGPR -> ds_write (A/B knob "a_stage")
     unsigned in_bytes, w_bytes;   // extents of the input tensor / weight pack for the SRDs
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
     // split-K across workgroups (NHWC epilogue): scratch for the f32 partial tiles and one arrival counter per
@@ -91,7 +92,7 @@ struct SeqLayer {
     signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
     signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
-    signed char pad_[1];
+    signed char a_stage;   // see ConvParams::a_stage
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
@@ -138,6 +139,7 @@ struct Tuning {
     int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 1;          // sequences: 128-row tiles for short-K layers that would otherwise need several 64-row rounds
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
+    int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
 };
 extern Tuning g_tune;
 

@@ -318,3 +318,41 @@ def test_conv_wreg_windows_and_upsample():
     for tile in ((64, 64), (128, 64)):
         y = ops.conv2d(torch.from_numpy(g).cuda(), w2, pad=1, ups=(31, 31), dtype="f16", algo="wreg", tile=tile)
         assert rel_err(y.cpu().numpy(), ref2) <= TOL["f16"], tile
+
+
+def test_conv_wreg_register_staged_rows_bit_equal():
+    """smk_tune a_stage=1: the producers of conv_wreg_kernel read the activation rows in ascending lane order into
+    registers and apply the LDS swizzle with ds_write_b128 instead of permuting the source address of an LDS-DMA.  The LDS
+    image and everything behind it are the same, so the outputs must be bit-identical for every workgroup shape and
+    geometry (padding, strides, dilation, taps straddling K tiles, per-stream windows, M tails, N overhang)."""
+    from siammask_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(77)
+    a_default = _lib.tune_get("a_stage")
+    try:
+        for cfg in WREG_CASES:
+            cin, cout, k, stride, pad, dil, hw, B, with_res = cfg
+            x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k), _rand(rng, cout)
+            ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            rd = torch.from_numpy(_rand(rng, B, cout, ho, ho)).cuda() if with_res else None
+            xd = torch.from_numpy(x).cuda()
+            for tile in WREG_TILES:
+                ys = []
+                for a in (0, 1):
+                    _lib.tune(a_stage=a)
+                    ys.append(ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16",
+                                         algo="wreg", tile=tile, stages=3).clone())
+                assert torch.equal(ys[0], ys[1]), (cfg, tile)
+        f = _rand(rng, 3, 64, 31, 31)
+        w = _rand(rng, 32, 64, 3, 3) / 24
+        pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
+        for tile in WREG_TILES:
+            ys = []
+            for a in (0, 1):
+                _lib.tune(a_stage=a)
+                ys.append(ops.conv2d(torch.from_numpy(f).cuda(), w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4,
+                                     dtype="f16", algo="wreg", tile=tile).clone())
+            assert torch.equal(ys[0], ys[1]), tile
+    finally:
+        _lib.tune(a_stage=a_default)
+
