@@ -63,11 +63,15 @@ template <int FM, int NSTAGE, int NCW = 4> struct WregLds {
 //
 // (Measured and removed, profiles/r02_wreg_pf_wave.txt: a seventh wave that touched the weight panel's lines 4-32 K tiles
 // ahead of the consumers to warm the XCD's L2 -- no effect on any layer, so the K-tile time is not first-touch L2 latency.)
-template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, class P = ConvParams>
+template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, int NPW = 2, class P = ConvParams>
 __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
                                           unsigned char *smem) {
     typedef _Float16 T;
-    constexpr int NCW = WN * WK, NPW = 2, NT = (NCW + NPW) * 64;
+    // NPW producer waves (2 or 4; smk_tune "npw"): tools/dma_patterns.hip measured that ONE loader wave beside MFMA waves
+    // sustains a fixed ~8-14 GB/s of LDS-DMA whatever it has in flight, and that the rate of a CU grows with the number of
+    // loader waves (2 -> 4 waves: x2) -- the activation stream of a 64-row tile is issue-bound on two producer waves
+    constexpr int NCW = WN * WK, NT = (NCW + NPW) * 64;
+    static_assert(NPW == 2 || NPW == 4, "two or four producer waves");
     // (eight consumers -- two MFMA-issuing waves per SIMD in one workgroup, 64x256 as 4x2 and 64x128 as 2x4 -- compile and
     // pass parity with this routine; measured 0-12 % slower than four on every layer, profiles/r02_wreg_ncw8.txt)
     static_assert(NCW == 4 && (WK == 1 || WK == 2 || WK == 4), "four consumer waves");
@@ -381,8 +385,8 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
 }
 
 // ---- one convolution (or a merged batch of independent ones) per launch ------------------------------------------
-template <int FM, int WN, int WK, int NSTAGE>
-__global__ __launch_bounds__((WN * WK + 2) * 64, (WregLds<FM, NSTAGE, WN * WK>::v <= 80 * 1024 ? 2 : 1))
+template <int FM, int WN, int WK, int NSTAGE, int NPW>
+__global__ __launch_bounds__((WN * WK + NPW) * 64, ((NPW == 2 && WregLds<FM, NSTAGE, WN * WK>::v <= 80 * 1024) ? 2 : 1))
 void conv_wreg_kernel(const ConvBatch cb) {
     int pi = 0;
 #pragma unroll
@@ -400,7 +404,7 @@ void conv_wreg_kernel(const ConvBatch cb) {
         t = x * q + (x < r ? x : r) + j;
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
-    wreg_tile<FM, WN, WK, NSTAGE, 0>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
+    wreg_tile<FM, WN, WK, NSTAGE, 0, 2, NPW>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
 }
 
 // measurement builds (smk_tune "ablate" = 1 no A refills, 2 no W refills, 4 no MFMA; results are wrong by construction)
@@ -447,7 +451,8 @@ __device__ __forceinline__ void team_barrier(unsigned *cnt, unsigned target, int
     __syncthreads();
 }
 
-__global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
+template <int NPW>
+__global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
     // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
     // over the XCDs, starting wherever the previous launch stopped, so blockIdx says nothing); slot = arrival ticket
@@ -480,13 +485,13 @@ __global__ __launch_bounds__(384, 1) void conv_seq_kernel(const SeqArgs a) {
             for (int t = slot; t < tiles; t += nslots) {
                 const int tm = t / tilesN, tn = t - tm * tilesN;
                 const int m0 = img * hw + tm * bm, m_end = (img + 1) * hw;
-                if (L.cfg == 0) wreg_tile<2, 4, 1, 3, 16>(L, 0, m0, m_end, tn * 256, smem);
-                else if (L.cfg == 1) wreg_tile<2, 2, 2, 3, 16>(L, 0, m0, m_end, tn * 128, smem);
+                if (L.cfg == 0) wreg_tile<2, 4, 1, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 256, smem);
+                else if (L.cfg == 1) wreg_tile<2, 2, 2, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 128, smem);
                 // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
-                else if (L.cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1>(L, 0, m0, m_end, tn * 256, smem);
-                else if (L.cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1>(L, 0, m0, m_end, tn * 128, smem);
-                else wreg_tile<2, 1, 4, 3, 16>(L, 0, m0, m_end, tn * 64, smem);
+                else if (L.cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 256, smem);
+                else if (L.cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 128, smem);
+                else wreg_tile<2, 1, 4, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 64, smem);
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (L.sync && li + 1 < a.n) {
@@ -540,8 +545,13 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
-    else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
+    if (g_tune.npw == 4) {
+        if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+        else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+    } else {
+        if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 2>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
+        else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 2>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -570,7 +580,8 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
 
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
     if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
-    hipLaunchKernelGGL(conv_seq_kernel, dim3(grid), dim3(384), 0, (hipStream_t)stream, a);
+    if (g_tune.npw == 4) hipLaunchKernelGGL(conv_seq_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_seq_kernel<2>, dim3(grid), dim3(384), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

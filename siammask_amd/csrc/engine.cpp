@@ -1578,6 +1578,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
+    else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
@@ -1596,7 +1597,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"mask_overlap", &g_tune.mask_overlap},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }

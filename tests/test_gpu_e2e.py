@@ -468,30 +468,31 @@ def test_persistent_sequences_and_tail_fusion_are_what_runs_at_b8():
         assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, k
 
 
-def test_register_staged_rows_bit_equal_end_to_end():
-    """smk_tune a_stage (activation rows of conv_wreg / conv_seq through registers instead of LDS-DMA) changes the data path
-    of the producers only: the fused B = 8 frame step (persistent sequences on) must give bit-identical outputs either way,
-    and the device error flag of the sequences stays 0."""
+def test_producer_variants_bit_equal_end_to_end():
+    """smk_tune a_stage (activation rows of conv_wreg / conv_seq through registers instead of LDS-DMA) and npw (two or four
+    producer waves) change the data path of the producers only: the fused B = 8 frame step (persistent sequences on) must
+    give bit-identical outputs for every combination, and the device error flag of the sequences stays 0."""
     from siammask_amd import _lib
     B = 8
     z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=90)).cuda()
     x = torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=90)).cuda()
     twh = torch.tensor([[70.0, 50.0]] * B, dtype=torch.float64).cuda()
     outs = []
-    a_default = _lib.tune_get("a_stage")
+    saved = {k: _lib.tune_get(k) for k in ("a_stage", "npw")}
+    variants = ((0, 2), (1, 2), (0, 4), (1, 4))
     try:
-        for a in (0, 1):
-            _lib.tune(a_stage=a)
+        for a, n in variants:
+            _lib.tune(a_stage=a, npw=n)
             m = _model("sharp", "synthetic_damped", "f16", True, max_batch=B)
             m.template(z)
             m.track_step(x, twh, refine=True)
             o = m.track_step(x, twh, refine=True)                  # second call = graph replay
             torch.cuda.synchronize()
             outs.append({k: v.clone() for k, v in o.items() if v is not None})
-            assert m.seq_status()[1] == 0
+            assert m.seq_status() == (256, 0), (a, n, m.seq_status())
             del m
     finally:
-        _lib.tune(a_stage=a_default)
-    for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
-
+        _lib.tune(**saved)
+    for v, o in zip(variants[1:], outs[1:]):
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], o[k]), (v, k)

@@ -320,15 +320,19 @@ def test_conv_wreg_windows_and_upsample():
         assert rel_err(y.cpu().numpy(), ref2) <= TOL["f16"], tile
 
 
-def test_conv_wreg_register_staged_rows_bit_equal():
-    """smk_tune a_stage=1: the producers of conv_wreg_kernel read the activation rows in ascending lane order into
-    registers and apply the LDS swizzle with ds_write_b128 instead of permuting the source address of an LDS-DMA.  The LDS
-    image and everything behind it are the same, so the outputs must be bit-identical for every workgroup shape and
-    geometry (padding, strides, dilation, taps straddling K tiles, per-stream windows, M tails, N overhang)."""
+PRODUCER_VARIANTS = ((0, 2), (1, 2), (0, 4), (1, 4))       # (a_stage, npw); the first one is the reference
+
+
+def test_conv_wreg_producer_variants_bit_equal():
+    """smk_tune a_stage / npw change only HOW the activation rows reach the LDS ring of conv_wreg_kernel: by LDS-DMA with
+    the swizzle on the source address or through registers in ascending lane order with the swizzle applied by
+    ds_write_b128 (a_stage), issued by two or by four producer waves (npw).  The LDS image and everything behind it are
+    the same, so the outputs must be bit-identical for every workgroup shape and geometry (padding, strides, dilation, taps
+    straddling K tiles, per-stream windows, M tails, N overhang)."""
     from siammask_amd import _lib
     ops = _ops()
     rng = np.random.default_rng(77)
-    a_default = _lib.tune_get("a_stage")
+    saved = {k: _lib.tune_get(k) for k in ("a_stage", "npw")}
     try:
         for cfg in WREG_CASES:
             cin, cout, k, stride, pad, dil, hw, B, with_res = cfg
@@ -338,21 +342,22 @@ def test_conv_wreg_register_staged_rows_bit_equal():
             xd = torch.from_numpy(x).cuda()
             for tile in WREG_TILES:
                 ys = []
-                for a in (0, 1):
-                    _lib.tune(a_stage=a)
+                for a, n in PRODUCER_VARIANTS:
+                    _lib.tune(a_stage=a, npw=n)
                     ys.append(ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16",
                                          algo="wreg", tile=tile, stages=3).clone())
-                assert torch.equal(ys[0], ys[1]), (cfg, tile)
+                for v, y in zip(PRODUCER_VARIANTS[1:], ys[1:]):
+                    assert torch.equal(ys[0], y), (cfg, tile, v)
         f = _rand(rng, 3, 64, 31, 31)
         w = _rand(rng, 32, 64, 3, 3) / 24
         pos = np.array([[0, 24], [12, 12], [24, 3]], dtype=np.int32)
         for tile in WREG_TILES:
             ys = []
-            for a in (0, 1):
-                _lib.tune(a_stage=a)
+            for a, n in PRODUCER_VARIANTS:
+                _lib.tune(a_stage=a, npw=n)
                 ys.append(ops.conv2d(torch.from_numpy(f).cuda(), w, pad=1, win=(15, 15), pos=pos, pos_mul=1, pos_add=-4,
                                      dtype="f16", algo="wreg", tile=tile).clone())
-            assert torch.equal(ys[0], ys[1]), tile
+            for v, y in zip(PRODUCER_VARIANTS[1:], ys[1:]):
+                assert torch.equal(ys[0], y), (tile, v)
     finally:
-        _lib.tune(a_stage=a_default)
-
+        _lib.tune(**saved)

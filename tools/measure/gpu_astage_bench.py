@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""conv_wreg_kernel with the activation rows by LDS-DMA (a_stage=0) against the register-staged rows (a_stage=1), per layer
-geometry and workgroup shape, beside the best LDS-staged instantiations (conv_igemm tiles, conv3x3_halo) of the same layer.
+"""conv_wreg_kernel with two settings of a producer knob -- by default the activation rows by LDS-DMA (a_stage=0, "a0" /
+"dma" below) against the register-staged rows (a_stage=1, "a1" / "regs"); AB_KNOB=npw AB_VALS=2,4 compares two against
+four producer waves -- per layer geometry and workgroup shape, beside the best LDS-staged instantiations (conv_igemm tiles,
+conv3x3_halo) of the same layer.
     python tools/measure/gpu_astage_bench.py 8[,64] gpurun_out/astage_bench.json
 One line per layer: us per launch of every candidate (30-launch averages, one process)."""
 import json
@@ -22,10 +24,14 @@ BASE = [((128, 128), 128, 2), ((64, 128), 128, 3), ((128, 64), 128, 3)]
 WREG = [(64, 256), (64, 128), (64, 64), (128, 256), (128, 128), (128, 64)]
 
 
+KNOB = os.environ.get("AB_KNOB", "a_stage")               # the producer knob under test and its two values
+VALS = [int(v) for v in os.environ.get("AB_VALS", "0,1").split(",")]
+
+
 def main():
     batches = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8]
     out_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/astage_bench.json"
-    a0 = _lib.tune_get("a_stage")
+    a0 = _lib.tune_get(KNOB)
     res, t0 = {}, time.time()
     for B in batches:
         res[B] = {}
@@ -51,13 +57,13 @@ def main():
                         runs["halo %d" % tile[0]] = "ERR %s" % str(e)[:60]
             for tile in WREG:
                 for a in (0, 1):
-                    _lib.tune(a_stage=a)
+                    _lib.tune(**{KNOB: VALS[a]})
                     try:
                         runs["wreg %dx%d a%d" % (tile[0], tile[1], a)] = ops.bench_conv(
                             B * bm, cin, hw, hw, cout, k, st, pad, dil, tile=tile, stages=3, wreg=True, **kw)
                     except Exception as e:  # noqa: BLE001
                         runs["wreg %dx%d a%d" % (tile[0], tile[1], a)] = "ERR %s" % str(e)[:60]
-            _lib.tune(a_stage=a0)
+            _lib.tune(**{KNOB: a0})
             ok = {k_: v for k_, v in runs.items() if isinstance(v, float)}
             old = {k_: v for k_, v in ok.items() if not k_.startswith("wreg")}
             w0 = {k_: v for k_, v in ok.items() if k_.endswith("a0")}
