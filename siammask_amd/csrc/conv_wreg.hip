@@ -69,10 +69,12 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
     typedef _Float16 T;
     // NPW producer waves (2 or 4; smk_tune "npw"): tools/dma_patterns.hip measured that ONE loader wave beside MFMA waves
     // sustains a fixed ~8-14 GB/s of LDS-DMA whatever it has in flight, and that the rate of a CU grows with the number of
-    // loader waves (2 -> 4 waves: x2) -- the activation stream of a 64-row tile is issue-bound on two producer waves
+    // loader waves (2 -> 4 waves: x2) -- the activation stream of a 64-row tile is issue-bound on two producer waves.
+    // Measured (profiles/r02_producer_waves_2_vs_4.txt): four producers x1.06-1.64 per layer, -7..8 % on the B=8 step, outputs
+    // bit-identical.  Eight (64-row tiles, 12 waves, one workgroup per CU): +0-8 % on some layers, -15 % on layer1, step
+    // unchanged -> removed (profiles/r02_producer_waves_4_vs_8.txt).
     constexpr int NCW = WN * WK, NT = (NCW + NPW) * 64;
-    static_assert(NPW == 2 || NPW == 4 || NPW == 8, "two, four or eight producer waves");
-    static_assert(NPW < 8 || FM == 2, "eight producer waves: 12 waves per workgroup leave 168 VGPRs, the 128-row tiles need 234");
+    static_assert(NPW == 2 || NPW == 4, "two or four producer waves");
     // (eight consumers -- two MFMA-issuing waves per SIMD in one workgroup, 64x256 as 4x2 and 64x128 as 2x4 -- compile and
     // pass parity with this routine; measured 0-12 % slower than four on every layer, profiles/r02_wreg_ncw8.txt)
     static_assert(NCW == 4 && (WK == 1 || WK == 2 || WK == 4), "four consumer waves");
@@ -477,8 +479,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
     if (clk) a.clk[0] = wall_clock64();
     for (int li = 0; li < a.n; ++li) {
         const SeqLayer &L = a.L[li];
-        // (eight producer waves: 64-row tiles only -- the 128-row shapes do not fit 168 VGPRs -- so cfg 3 / 4 run as 0 / 1)
-        const int cfg = (NPW == 8 && L.cfg >= 3) ? L.cfg - 3 : L.cfg;
+        const int cfg = L.cfg;
         const int bn = (cfg == 0 || cfg == 3) ? 256 : ((cfg == 1 || cfg == 4) ? 128 : 64);
         const int bm = cfg >= 3 ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
@@ -492,8 +493,8 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 else if (cfg == 1) wreg_tile<2, 2, 2, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 128, smem);
                 // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
-                else if (cfg == 3) { if constexpr (NPW < 8) wreg_tile<4, 4, 1, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 256, smem); }
-                else if (cfg == 4) { if constexpr (NPW < 8) wreg_tile<4, 2, 2, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 128, smem); }
+                else if (cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 256, smem);
+                else if (cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 128, smem);
                 else wreg_tile<2, 1, 4, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 64, smem);
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
@@ -548,13 +549,7 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    if constexpr (FM == 2)
-    if (g_tune.npw == 8) {
-        if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 8>), grid, dim3((WN * WK + 8) * 64), 0, s, cb);
-        else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 8>), grid, dim3((WN * WK + 8) * 64), 0, s, cb);
-        return hipGetLastError() == hipSuccess ? 0 : -4;
-    }
-    if (g_tune.npw >= 4) {
+    if (g_tune.npw == 4) {
         if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
         else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
     } else {
@@ -589,8 +584,7 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
 
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
     if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
-    if (g_tune.npw == 8) hipLaunchKernelGGL(conv_seq_kernel<8>, dim3(grid), dim3(768), 0, (hipStream_t)stream, a);
-    else if (g_tune.npw == 4) hipLaunchKernelGGL(conv_seq_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (g_tune.npw == 4) hipLaunchKernelGGL(conv_seq_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_seq_kernel<2>, dim3(grid), dim3(384), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

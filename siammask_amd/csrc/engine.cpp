@@ -1578,7 +1578,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
-    else if (!strcmp(key, "npw")) { if (value != 2 && value != 4 && value != 8) return fail(SMK_E_ARG, "npw 2|4|8"); g_tune.npw = value; }
+    else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }

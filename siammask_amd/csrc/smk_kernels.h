@@ -139,7 +139,7 @@ struct Tuning {
     int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 1;          // sequences: 128-row tiles for short-K layers that would otherwise need several 64-row rounds
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
-    int npw = 2;               // conv_wreg / conv_seq: producer waves per workgroup (2, 4 or 8; 8 applies to the 64-row tiles, the 128-row ones stay at 4)
+    int npw = 4;               // conv_wreg / conv_seq: producer waves per workgroup (2 or 4; measured: profiles/r02_producer_waves_2_vs_4.txt)
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
 };
 extern Tuning g_tune;

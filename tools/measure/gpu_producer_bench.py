@@ -3,7 +3,7 @@
 "dma" below) against the register-staged rows (a_stage=1, "a1" / "regs"); AB_KNOB=npw AB_VALS=2,4 compares two against
 four producer waves -- per layer geometry and workgroup shape, beside the best LDS-staged instantiations (conv_igemm tiles,
 conv3x3_halo) of the same layer.
-    python tools/measure/gpu_astage_bench.py 8[,64] gpurun_out/astage_bench.json
+    python tools/measure/gpu_producer_bench.py 8[,64] gpurun_out/astage_bench.json
 One line per layer: us per launch of every candidate (30-launch averages, one process)."""
 import json
 import os
@@ -69,13 +69,15 @@ def main():
             w0 = {k_: v for k_, v in ok.items() if k_.endswith("a0")}
             w1 = {k_: v for k_, v in ok.items() if k_.endswith("a1")}
             bo, b0, b1 = min(old, key=old.get), min(w0, key=w0.get), min(w1, key=w1.get)
+            t0n, t1n = "%s=%d" % (KNOB, VALS[0]), "%s=%d" % (KNOB, VALS[1])
             res[B][name] = {"gflop": round(gflop, 3), "best_lds_staged": bo, "lds_staged_us": round(old[bo], 2),
-                            "best_wreg_dma": b0, "wreg_dma_us": round(w0[b0], 2),
-                            "best_wreg_regs": b1, "wreg_regs_us": round(w1[b1], 2),
+                            "knob": KNOB, "a0": VALS[0], "a1": VALS[1],
+                            "best_wreg_a0": b0, "wreg_a0_us": round(w0[b0], 2),
+                            "best_wreg_a1": b1, "wreg_a1_us": round(w1[b1], 2),
                             "runs": {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in runs.items()}}
-            print("B=%d %-12s %7.2f GF | lds-staged %-14s %7.2f | wreg dma %-16s %7.2f | wreg regs %-16s %7.2f us  "
-                  "regs/dma x%.2f  [%.0fs]" % (B, name, gflop, bo, old[bo], b0, w0[b0], b1, w1[b1], w0[b0] / w1[b1],
-                                              time.time() - t0), flush=True)
+            print("B=%d %-12s %7.2f GF | lds-staged %-14s %7.2f | wreg %s %-8s %7.2f | wreg %s %-8s %7.2f us  x%.2f  [%.0fs]" % (
+                B, name, gflop, bo, old[bo], t0n, b0[5:-3], w0[b0], t1n, b1[5:-3], w1[b1], w0[b0] / w1[b1],
+                time.time() - t0), flush=True)
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
 
