@@ -769,6 +769,28 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     // reductions with K >= 512 (l3.c1 x1.13, l3.0.c1 x1.10, l2.c1 x1.07) and the strided 3x3 of l2.0 (x1.06).
     // It loses on layer1 (short K, large M: x0.5-0.9) and against the halo kernel on 3x3 stride-1 layers.
     const long K = (long)p.kh * p.kw * p.Ci;
+    if (g_tune.wreg_policy == 1) {
+        // With four producer waves (smk_tune npw, round 2) the register-fed kernel beats the best LDS-staged instantiation on
+        // almost every fp16 NHWC layer of the path at B = 1, 8 and 64 (profiles/r02_producer_waves_2_vs_4.txt,
+        // r02_producer_waves_layers_b1_b64.json).  Exceptions, kept on the LDS-staged kernels: the 7x7 stem, the short-K 3x3
+        // stride-1 layers (the patch-sharing kernel wins or ties: l1.c2, l2.c2, Refine's small convolutions), and at
+        // large M the narrow / short-K layers (128-row LDS-staged tiles at two workgroups per CU win: layer1, l2.c1, head0,
+        // v1.0 at B = 64).
+        if (p.kh > 3) return 0;
+        if (p.kh == 3 && p.stride == 1 && K <= 1152) return 0;
+        if (p.M > 16384 && !(p.Nst >= 512 || (K >= 2304 && p.Nst >= 128) || (K >= 1024 && p.Nst >= 256) ||
+                             (p.kh == 3 && p.stride == 2)))
+            return 0;
+        // the largest workgroup shape that still hands the chip >= 150 workgroups (N-wide first: 128x256, 64x256, 64x128, 64x64)
+        static const int cand[4] = {4, 1, 2, 3};
+        const int nr = (p.Nst + 63) / 64 * 64, ng = p.groups > 0 ? p.groups : 1;
+        for (int ci = 0; ci < 4; ++ci) {
+            const int bm = WREG_TILE[cand[ci]][0], bn = WREG_TILE[cand[ci]][1];
+            if (bn > nr && bn > 64) continue;
+            if ((long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * ng >= 150) return cand[ci];
+        }
+        return 3;
+    }
     if (p.M < 4096) return 0;                  // not measured below B ~ 5: keep the fitted LDS-staged choice
     if (p.kh == 3 && K >= 2304 && p.Nst >= 512)
         return ((long)((p.M + 127) / 128) * ((p.Nst + 255) / 256) >= 200) ? 4 : 1;       // 128x256 once it fills the chip
@@ -811,7 +833,9 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     int rc = 1;
     int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
     if (bm && !o.halo && conv_ksplit(p, c->dtype, t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
-    const int wr = (o.halo || (bm && !o.wreg && g_tune.wreg < 2)) ? 0 : wreg_choice(p, o, c->dtype);
+    // (policy 1 decides between the register-fed and the patch-sharing kernel itself; the round-2 table only covered the
+    //  layers the patch-sharing kernel does not take)
+    const int wr = (o.halo || (bm && !o.wreg && g_tune.wreg < 2 && g_tune.wreg_policy == 0)) ? 0 : wreg_choice(p, o, c->dtype);
     if (wr) {
         // weights straight into registers, activations through LDS
         ConvBatch cb;
@@ -1578,6 +1602,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
+    else if (!strcmp(key, "wreg_policy")) { if (value != 0 && value != 1) return fail(SMK_E_ARG, "wreg_policy 0|1"); g_tune.wreg_policy = value; }
     else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
@@ -1597,7 +1622,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"mask_overlap", &g_tune.mask_overlap},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
