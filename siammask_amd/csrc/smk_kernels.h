@@ -139,7 +139,7 @@ struct Tuning {
     int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 1;          // sequences: 128-row tiles for short-K layers that would otherwise need several 64-row rounds
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
-    int wreg_policy = 0;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer
+    int wreg_policy = 1;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer
                                // waves), 1 = the rule fitted with four (wreg_choice)
     int npw = 4;               // conv_wreg / conv_seq: producer waves per workgroup (2 or 4; measured: profiles/r02_producer_waves_2_vs_4.txt)
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
