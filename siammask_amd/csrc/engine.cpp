@@ -699,7 +699,9 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     // ~5 us against ~0.45 us per K tile, SMK_SEQ_CLK), so when the 64-row tiling needs more than one round of the team's
     // 32 workgroups per image, ONE 128-row tile per workgroup beats two 64-row tiles in sequence
     // (bottleneck conv3: 2 x 64x256 -> 1 x 128x256; layer2.0 conv1 on the 63x63 input: 4 rounds of 64x64 -> 1 of 128x128)
-    if (g_tune.seq_tall && (long)p.kh * p.kw * p.Ci <= 512) {
+    // (seq_tall = 2, A/B knob: also for long-K layers -- l3.0.downsample, 64 tiles of 64x256 = two rounds -- now that four
+    //  producer waves feed a 128-row tile)
+    if (g_tune.seq_tall && ((long)p.kh * p.kw * p.Ci <= 512 || g_tune.seq_tall == 2)) {
         const int hw = p.Ho * p.Wo;
         const int bn64 = L.cfg == 0 ? 256 : (L.cfg == 1 ? 128 : 64);
         const int tiles64 = ((hw + 63) / 64) * ((p.Nst + bn64 - 1) / bn64);
@@ -1590,7 +1592,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
     else if (!strcmp(key, "ablate")) g_tune.ablate = value & 7;
-    else if (!strcmp(key, "seq_tall")) g_tune.seq_tall = value != 0;
+    else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
