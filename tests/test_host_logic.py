@@ -165,3 +165,23 @@ def test_pack_cache_key_follows_the_checkpoint(tmp_path):
     assert b._pack_path(sd) != p0
     c = build("base", dtype="f16", pack_cache=str(tmp_path))
     assert c._pack_path(sd) != p0
+
+
+def test_tuning_knobs_read_back():
+    """smk_tune / smk_tune_get need no GPU: a knob reads back what was set, unknown names and out-of-range values are errors,
+    and the defaults are the measured ones (four producer waves, the layer rule fitted with them, 128-row sequence tiles)."""
+    from siammask_amd import _lib
+    assert (_lib.tune_get("npw"), _lib.tune_get("wreg_policy"), _lib.tune_get("seq_tall"), _lib.tune_get("a_stage")) == (4, 1, 2, 0)
+    old = _lib.tune_get("npw")
+    try:
+        _lib.tune(npw=2)
+        assert _lib.tune_get("npw") == 2
+        with pytest.raises(RuntimeError):
+            _lib.tune(npw=3)
+        assert _lib.tune_get("npw") == 2
+    finally:
+        _lib.tune(npw=old)
+    with pytest.raises(RuntimeError):
+        _lib.tune_get("no_such_knob")
+    with pytest.raises(RuntimeError):
+        _lib.tune(no_such_knob=1)
