@@ -57,6 +57,44 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1):
     return out
 
 
+def conv2d_f32acc(x, w, b=None, stride=1, pad=0, dil=1, kstep=16, ktile=64, ksplit=1):
+    """conv2d with the ACCUMULATION MODEL of the MFMA kernels instead of exact sums: K ordered (kh, kw, cin) as the packed
+    weights are (smk_kernels.h), every k-step of `kstep` elements is one matrix instruction (products and the in-step sum
+    taken as exact, the result rounded once into the float32 accumulator), K tiles of `ktile` elements are dealt round-robin
+    to `ksplit` accumulators per k-step position (the WK consumer waves of a workgroup each take every WK-th k-step of a K
+    tile) that are added in float32 at the end, then bias.  Inputs / outputs float64 arrays holding fp16-representable
+    values, as in QuantOracle.  This is ONE plausible order; the kernels use several (tile shape and K split differ per
+    layer and batch size) -- the point of the model is to measure how much the order alone moves the outputs."""
+    B, C, H, W = x.shape
+    Co, Ci, kh, kw = w.shape
+    assert Ci == C
+    if pad:
+        x = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    Hp, Wp = x.shape[2], x.shape[3]
+    Ho = (Hp - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Wp - dil * (kw - 1) - 1) // stride + 1
+    sB, sC, sH, sW = x.strides
+    cols = np.lib.stride_tricks.as_strided(
+        x, shape=(B, kh, kw, C, Ho, Wo),
+        strides=(sB, sH * dil, sW * dil, sC, sH * stride, sW * stride), writeable=False)
+    cols = np.ascontiguousarray(cols.reshape(B, kh * kw * C, Ho * Wo))
+    wk = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(Co, kh * kw * C))
+    K = kh * kw * C
+    acc = [np.zeros((B, Co, Ho * Wo), dtype=np.float32) for _ in range(ksplit)]
+    steps_per_tile = max(1, ktile // kstep)
+    for i, k0 in enumerate(range(0, K, kstep)):
+        part = np.matmul(wk[:, k0:k0 + kstep], cols[:, k0:k0 + kstep, :])            # float64: exact enough for 16 terms
+        a = acc[(i % steps_per_tile) % ksplit]
+        a += part.astype(np.float32)                                                # one float32 rounding per k-step
+    out = acc[0]
+    for a in acc[1:]:
+        out = out + a
+    out = out.astype(np.float64).reshape(B, Co, Ho, Wo)
+    if b is not None:
+        out = (out.astype(np.float32) + b.reshape(1, -1, 1, 1).astype(np.float32)).astype(np.float64)
+    return out
+
+
 def batchnorm_eval(x, gamma, beta, mean, var):
     """nn.BatchNorm2d in eval(): y = (x - mean) / sqrt(var + eps) * gamma + beta."""
     inv = gamma / np.sqrt(var + BN_EPS)
@@ -282,11 +320,15 @@ class QuantOracle(Oracle):
       * tensors handed back to the caller (cls, loc, mask, refine logits) are fp32: not rounded.
     Same call surface as ``Oracle``."""
 
-    def __init__(self, sd, variant="sharp", refine_sum_in_h=True):
+    def __init__(self, sd, variant="sharp", refine_sum_in_h=True, accum="exact", ksplit=1):
         super(QuantOracle, self).__init__(sd, variant, np.float64)
         # which of Refine's two branch outputs is stored (rounded) before the sum: True = v*.2 (the default
         # device path, refine_chain.hip), False = h*.2 (the per-layer path, SMK_TUNE=chain=0)
         self.refine_sum_in_h = refine_sum_in_h
+        # accumulation model of the convolutions: "exact" (float64 sums, the default) or "f32" (conv2d_f32acc: float32
+        # accumulator, one rounding per 16-element k-step in the device's K order, `ksplit` interleaved accumulators)
+        assert accum in ("exact", "f32")
+        self.accum, self.ksplit = accum, ksplit
 
     def _fold(self, conv, bn=None):
         w = self.sd[conv + ".weight"]
@@ -303,7 +345,10 @@ class QuantOracle(Oracle):
     def _fused(self, x, conv, bn=None, stride=1, pad=0, dil=1, act=False, res=None, res_after_relu=False,
                store=True):
         w, b = self._fold(conv, bn)
-        y = conv2d(x, w, b, stride, pad, dil)
+        if self.accum == "f32":
+            y = conv2d_f32acc(x, w, b, stride, pad, dil, ksplit=self.ksplit)
+        else:
+            y = conv2d(x, w, b, stride, pad, dil)
         if res is not None and not res_after_relu:
             y = y + res
         if act:

@@ -90,3 +90,31 @@ def test_quant_oracle_tracks_the_reference():
     assert rel_err(cls, g["cls"]) < 3e-2 and rel_err(loc, g["loc"]) < 3e-2
     assert rel_err(refs[True], g["refine"]) < 1e-2 and rel_err(refs[False], g["refine"]) < 1e-2
     assert 0 < rel_err(refs[True], refs[False]) < 5e-3
+
+
+def test_summation_order_alone_moves_the_fp16_outputs_by_the_tight_gate():
+    """Why the fp16 gate against the quantisation-aware oracle is 5e-3 and not the 2e-3 SURVEY.md proposed (round-1
+    verdict, item 10).  The SAME quantised network (fp16 weights, fp16 stored activations) evaluated with three summation
+    models -- exact sums, a float32 accumulator fed one 16-element k-step at a time in the device's K order
+    (conv2d_f32acc), the same with two interleaved accumulators (a K split inside the workgroup) -- differs from itself by
+    ~5e-4 after the stem, ~1.5e-3 after layer2 and ~3e-3 at `search`: every flipped fp16 rounding is amplified by the
+    network.  The kernels use several orders (tile shape and K split per layer and batch size), so no oracle order can pin
+    the device below that floor; the measured device-vs-oracle errors (3e-4 ... 3.4e-3) sit right on it.
+    The argmax of the decode is the same for all models."""
+    from oracle.np_oracle import QuantOracle, decode_best
+    sd = synth.state_dict("sharp", "synthetic_damped")
+    z = synth.smooth_image_batch(1, 127, stream0=5).astype(np.float64)
+    x = synth.smooth_image_batch(1, 255, stream0=5).astype(np.float64)
+    runs = {}
+    for name, kw in (("exact", {}), ("f32", {"accum": "f32"}), ("f32x2", {"accum": "f32", "ksplit": 2})):
+        q = QuantOracle(sd, "sharp", **kw)
+        q.template(z)
+        cls, loc, mask = q.track_mask(x)
+        runs[name] = dict(cls=cls, loc=loc, mask=mask, refine=q.track_refine((12, 12)), search=q.search,
+                          p0=q.feature[0], p2=q.feature[2], bid=decode_best(cls[0], loc[0])[0])
+    assert len({r["bid"] for r in runs.values()}) == 1
+    for a, b in (("exact", "f32"), ("f32", "f32x2")):
+        e = {k: rel_err(runs[b][k], runs[a][k]) for k in ("p0", "p2", "search", "cls", "loc", "mask", "refine")}
+        assert 1e-4 <= e["p0"] <= 1e-3, (a, b, e)                   # one layer: a few flipped roundings
+        assert 1.5e-3 <= e["search"] <= 5e-3, (a, b, e)             # ... amplified through 50 layers: above 2e-3, below the gate
+        assert all(v <= 5e-3 for v in e.values()), (a, b, e)
