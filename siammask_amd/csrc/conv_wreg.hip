@@ -9,10 +9,12 @@
 // global -> VGPR with fully coalesced 1 KB buffer loads, two K tiles ahead in a register ring (the compiler's counted
 // vmcnt(13..15) waits, checked in the ISA).  LDS reads per MFMA halve (FM = 2) or quarter per flop (FM = 4: 128 x 64
 // wave tiles), the LDS-DMA writes drop to the A rows, the weight stream never touches LDS.
-// Measured (profiles/r02_wregbench_b8_b64.json): +5..15 % on the long-K N-wide layers, slower on short-K large-M layers
-// -- LDS bandwidth (256 B/clk for ds_read_b128 on CDNA4) was NOT what bounded the LDS-staged kernel; DESIGN.md 3.1g.
+// Measured with TWO producer waves (profiles/r02_wregbench_b8_b64.json): +5..15 % on the long-K N-wide layers, slower on
+// short-K large-M layers -- LDS bandwidth (256 B/clk for ds_read_b128 on CDNA4) was NOT what bounded the LDS-staged kernel;
+// DESIGN.md 3.1g.  With FOUR (a loader wave beside an MFMA-issuing wave is issue-bound): x1.06-1.64 per layer,
+// faster than the best LDS-staged instantiation on almost every layer of the path at B = 1, 8 and 64.
 //
-//   workgroup  = 4 consumer waves (WN x WK) + 2 producer waves (A rows only, LDS-DMA, XOR swizzle on the source)
+//   workgroup  = 4 consumer waves (WN x WK) + NPW = 4 (or 2) producer waves (A rows only, LDS-DMA, XOR swizzle on the source)
 //   wave tile  = (32*FM) x 64;  workgroup tile = (32*FM) x (64*WN);  WK > 1 splits the k-steps of a K tile
 //   K tile     = 128 B (64 halves), NSTAGE-deep A ring, ONE s_barrier per K tile (same protocol as conv_igemm_kernel)
 // f16 only, NHWC epilogue only (the callers fall back to conv_igemm_kernel otherwise).
@@ -56,8 +58,8 @@ template <int FM, int NSTAGE, int NCW = 4> struct WregLds {
     static constexpr int v = WMax<NSTAGE * 32 * FM * 128, NCW * 32 * FM * 68 * 4>::v;
 };
 
-// ONE output tile rows [m0, min(m0 + BM, m_end)) x channels [n0, n0 + BN) of group g.  Called by all 384 threads of the
-// workgroup; starts and ends with the LDS free.  AUX = cache policy of the ACTIVATION loads (A rows, residual): 0 in
+// ONE output tile rows [m0, min(m0 + BM, m_end)) x channels [n0, n0 + BN) of group g.  Called by all (4 + NPW) * 64 threads of
+// the workgroup; starts and ends with the LDS free.  AUX = cache policy of the ACTIVATION loads (A rows, residual): 0 in
 // the one-conv-per-launch kernel, sc1 (16: served by the L2, never by this CU's L1) in the persistent sequence kernel,
 // where those bytes were written by another CU of the same XCD a moment ago.
 //
