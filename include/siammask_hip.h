@@ -258,6 +258,12 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
 int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, const float *b,
                        const float *res, const int32_t *pos, float *y);
 
+/* Host only: which kernel the engine picks for ONE convolution of this geometry and batch (g->B streams) under the current
+ * smk_tune knobs -- *kernel = 0 conv_igemm_kernel, 1 conv3x3_halo_kernel, 2 conv_wreg_kernel; *bm x *bn = workgroup shape;
+ * *seq_cfg = tile code inside a persistent per-XCD sequence (0 64x256, 1 64x128, 2 64x64, 3 128x256, 4 128x128) or -1 when
+ * the layer cannot be part of one.  Lets the CPU test-suite pin the measured layer rules (profiles/r02_producer_waves_*). */
+int smk_host_plan_conv(const smk_conv_geom *g, int dtype, int with_res, int *kernel, int *bm, int *bn, int *seq_cfg);
+
 #ifdef __cplusplus
 }
 #endif

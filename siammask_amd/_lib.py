@@ -26,7 +26,7 @@ SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
     "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status",
     "smk_debug_read", "smk_tune", "smk_tune_get", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
-    "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
+    "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_host_plan_conv", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
 )
 
@@ -93,6 +93,7 @@ def lib():
     L.smk_op_dw_xcorr.argtypes = [ci, fp, fp, ci, ci, ci, ci, ci, ci, fp, vp]
     L.smk_op_maxpool3x3s2.argtypes = [ci, fp, ci, ci, ci, ci, fp, vp]
     L.smk_host_conv2d_ex.argtypes = [gp, fp, fp, fp, fp, vp, fp]
+    L.smk_host_plan_conv.argtypes = [gp, ci, ci, ip, ip, ip, ip]
     L.smk_packed_size.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.smk_export_packed.argtypes = [vp, vp, ctypes.c_uint64]
     L.smk_import_packed.argtypes = [vp, vp, ctypes.c_uint64]

@@ -2195,4 +2195,39 @@ int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, c
     return 0;
 }
 
+// Which kernel and workgroup shape does the engine pick for one convolution of this geometry?  Host only (CPU tests pin the
+// measured layer rules with it).  Mirrors the decision order of run_conv: register-fed kernel (wreg_choice), else the
+// patch-sharing kernel (halo_choice), else the generic one (tile_from_code); *seq_cfg = the conv_seq_kernel tile code the layer
+// gets inside a persistent sequence, or -1 when it cannot be part of one.
+int smk_host_plan_conv(const smk_conv_geom *g, int dtype, int with_res, int *kernel, int *bm, int *bn, int *seq_cfg) {
+    if (!g || !kernel || !bm || !bn || !seq_cfg) return fail(SMK_E_ARG, "smk_host_plan_conv: null argument");
+    if (dtype != DT_F32 && dtype != DT_F16) return fail(SMK_E_ARG, "smk_host_plan_conv: dtype");
+    PackedConv pc; Act in; ConvOpt o; int Ho, Wo;
+    CHK(fill_geom(g, pc, in, o, Ho, Wo));
+    static float dummy[64];
+    in.p = dummy;
+    pc.w = dummy; pc.bias = dummy;
+    if (g->k == 3) pc.w_halo = dummy;
+    if (dtype == DT_F16) pc.w_frag = dummy;
+    Act out, res;
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8); out.p = dummy;
+    res = out;
+    if (with_res) { o.res = &res; o.res_mode = RES_PRE_RELU; }
+    smk_ctx fake;
+    fake.device = -1;
+    fake.dtype = dtype;
+    ConvParams p;
+    CHK(conv_params(&fake, pc, in, &out, g->B, o, p));
+    const TileChoice t = tile_from_code(0, p, dtype);
+    int hb = halo_choice(pc, p, o, dtype);
+    if (hb && conv_ksplit(p, dtype, t) > 1) hb = 0;
+    const int wr = (hb && g_tune.wreg < 2 && g_tune.wreg_policy == 0) ? 0 : wreg_choice(p, o, dtype);
+    if (wr) { *kernel = 2; *bm = WREG_TILE[wr][0]; *bn = WREG_TILE[wr][1]; }
+    else if (hb) { *kernel = 1; *bm = hb; *bn = 128; }
+    else { *kernel = 0; *bm = t.bm; *bn = t.bn; }
+    SeqLayer L;
+    *seq_cfg = seq_layer_from(p, dtype, L) ? (int)L.cfg : -1;
+    return 0;
+}
+
 }  // extern "C"

@@ -185,3 +185,54 @@ def test_tuning_knobs_read_back():
         _lib.tune_get("no_such_knob")
     with pytest.raises(RuntimeError):
         _lib.tune(no_such_knob=1)
+
+
+def _plan(B, cin, hw, cout, k, stride=1, pad=0, dil=1, res=False, win=None, dtype="f16"):
+    g = _lib.ConvGeom()
+    g.B, g.Cin, g.H, g.W = B, cin, hw, hw
+    g.Cout, g.k, g.stride, g.pad, g.dil = cout, k, stride, pad, dil
+    g.relu = 1
+    if win is not None:
+        g.win, g.Hl, g.Wl = 1, win, win
+    out = [ctypes.c_int(0) for _ in range(4)]
+    _lib.check(_lib.lib().smk_host_plan_conv(ctypes.byref(g), _lib.DTYPE[dtype], int(res), *[ctypes.byref(o) for o in out]))
+    kernel, bm, bn, cfg = [o.value for o in out]
+    return ("igemm", "halo", "wreg")[kernel], (bm, bn), cfg
+
+
+def test_layer_rules_are_the_measured_ones():
+    """The kernel / workgroup-shape choice per layer is fitted to measurements (profiles/r02_producer_waves_2_vs_4.txt,
+    r02_producer_waves_layers_b1_b64.json, r02b_seq_layer_clocks.txt).  smk_host_plan_conv exposes it without a GPU, so a
+    change of the rule shows up here instead of as a silent slowdown.  (kernel, workgroup shape, tile code inside a
+    persistent sequence or -1)."""
+    # B = 8 (headline): layer2 / layer3 / adjust run inside the sequences -> the sequence tile code is what counts
+    assert _plan(8, 1024, 31, 256, 1)[2] == 1                                  # l3.c1   64x128
+    assert _plan(8, 256, 31, 256, 3, pad=2, dil=2)[2] == 1                     # l3.c2   64x128
+    assert _plan(8, 256, 31, 1024, 1, res=True)[2] == 3                        # l3.c3   128x256 (two 64-row rounds otherwise)
+    assert _plan(8, 512, 31, 1024, 3, pad=1)[2] == 3                           # l3.0.ds 128x256 (long K too, seq_tall = 2)
+    assert _plan(8, 256, 63, 512, 3, stride=2)[2] == 0                         # l2.0.ds 64x256 (one round)
+    assert _plan(8, 256, 63, 128, 1)[2] == 4                                   # l2.0.c1 on the 63x63 input: 128x128
+    assert _plan(8, 128, 31, 128, 3, pad=1)[2] == 2                            # l2.c2   64x64
+    assert _plan(8, 128, 31, 512, 1, res=True)[2] == 0                         # l2.c3   64x256
+    # B = 8 per launch
+    assert _plan(8, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))               # conv_search (N-fused 768)
+    assert _plan(8, 64, 63, 64, 3, pad=1)[0] == "halo"                         # l1.c2: short-K 3x3 stays on the patch kernel
+    assert _plan(8, 64, 63, 256, 1, res=True)[:2] == ("igemm", (128, 128))     # l1.c3: large M, short K
+    assert _plan(8, 256, 63, 64, 1)[0] == "igemm"                              # l1.c1
+    assert _plan(8, 3, 255, 64, 7, stride=2)[0] == "igemm"                     # stem
+    assert _plan(8, 512, 31, 128, 3, pad=1, win=15)[:2] == ("wreg", (64, 64))  # Refine v2.0 on its own
+    # B = 1: almost everything on the register-fed kernel, 64x64 tiles
+    for args in ((1024, 31, 256, 1), (256, 31, 1024, 1), (512, 31, 128, 1), (256, 63, 64, 1)):
+        assert _plan(1, *args)[:2] == ("wreg", (64, 64)), args
+    assert _plan(1, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (64, 64))   # l3.c2
+    assert _plan(1, 128, 31, 128, 3, pad=1)[0] == "halo"                       # l2.c2 (K = 1152)
+    # B = 64: wide / long-K layers on 128x256 register-fed tiles, narrow short-K ones on LDS-staged 128-row tiles
+    assert _plan(64, 1024, 31, 256, 1)[:2] == ("wreg", (128, 256))             # l3.c1
+    assert _plan(64, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (128, 256))  # l3.c2
+    assert _plan(64, 256, 31, 1024, 1, res=True)[:2] == ("wreg", (128, 256))   # l3.c3
+    assert _plan(64, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))              # conv_search
+    assert _plan(64, 512, 31, 128, 1)[0] == "igemm"                            # l2.c1
+    assert _plan(64, 256, 63, 64, 1)[0] == "igemm"                             # l1.c1
+    assert _plan(64, 128, 31, 128, 3, pad=1)[0] == "halo"                      # l2.c2
+    # fp32: no register-fed kernel, no sequences
+    assert _plan(8, 1024, 31, 256, 1, dtype="f32")[0] == "igemm" and _plan(8, 1024, 31, 256, 1, dtype="f32")[2] == -1
