@@ -65,9 +65,12 @@ template <int FM, int NSTAGE, int NCW = 4> struct WregLds {
 //
 // (Measured and removed, profiles/r02_wreg_pf_wave.txt: a seventh wave that touched the weight panel's lines 4-32 K tiles
 // ahead of the consumers to warm the XCD's L2 -- no effect on any layer, so the K-tile time is not first-touch L2 latency.)
-template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, int NPW = 2, class P = ConvParams>
+// (CLK = 1, measurement build of conv_seq_kernel only: thread 0 stamps the phases of the tile into tclk[0..6] -- entry, first
+//  activation tile in LDS, K loop done, workgroup past the loop, accumulators handed over, stores issued, tile done.  CLK = 0
+//  compiles to exactly the code without it.)
+template <int FM, int WN, int WK, int NSTAGE, int AUX, int WT = 2, int NPW = 2, int CLK = 0, class P = ConvParams>
 __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0, const int m_end, const int n0,
-                                          unsigned char *smem) {
+                                          unsigned char *smem, unsigned long long *tclk = nullptr) {
     typedef _Float16 T;
     // NPW producer waves (2 or 4; smk_tune "npw"): tools/dma_patterns.hip measured that ONE loader wave beside MFMA waves
     // sustains a fixed ~8-14 GB/s of LDS-DMA whatever it has in flight, and that the rate of a CU grows with the number of
@@ -93,6 +96,12 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto stamp = [&](int i) {
+        if constexpr (CLK != 0) {
+            if (tclk && tid == 0) tclk[i] = wall_clock64();
+        }
+    };
+    stamp(0);
     const int cout_off = p.cout_off + g * p.g_cout_off;
     const float *bias = p.bias + g * p.g_wgt_off;
     const int nk = p.Kpad / BK;                   // K tiles (Kpad is a multiple of 128 elements: nk is even)
@@ -276,6 +285,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
         for (int j = 0; j < D; ++j) load_w(j, fb[j]);
         __builtin_amdgcn_s_barrier();                           // barrier(0): A tile 0 is complete
         asm volatile("" ::: "memory");
+        stamp(1);
         read_a(0, 0, fa[0]);
         int cur = 0;                                            // ring slot of the current A tile
         // one macro-iteration = D steps = two K tiles; REFILL: re-load the ring slot just consumed for step g + D
@@ -311,8 +321,10 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
         int g0 = 0;
         for (; g0 + D < S; g0 += D) body(g0, std::true_type{}, std::false_type{});
         body(g0, std::false_type{}, std::true_type{});
+        stamp(2);
     }
     __syncthreads();
+    stamp(3);
 
     // ---- epilogue: accumulators -> LDS -> (sum over the K-group) -> bias / residual / ReLU -> NHWC f16 ----------
     constexpr int EV = 8;
@@ -353,6 +365,7 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
                 }
     }
     __syncthreads();
+    stamp(4);
     if (ncol_ok) {
         const float *ecol = (const float *)smem + ((c4 >> 6) * WK) * (BM * LDE) + (c4 & 63);
         float bv[EV];
@@ -386,7 +399,9 @@ __device__ __forceinline__ void wreg_tile(const P &p, const int g, const int m0,
             }
         }
     }
+    stamp(5);
     __syncthreads();                                     // the LDS is free again (the next tile's producers may start)
+    stamp(6);
 }
 
 // ---- one convolution (or a merged batch of independent ones) per launch ------------------------------------------
@@ -456,7 +471,7 @@ __device__ __forceinline__ void team_barrier(unsigned *cnt, unsigned target, int
     __syncthreads();
 }
 
-template <int NPW>
+template <int NPW, int CLK = 0>
 __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
     // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
@@ -491,13 +506,16 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
             for (int t = slot; t < tiles; t += nslots) {
                 const int tm = t / tilesN, tn = t - tm * tilesN;
                 const int m0 = img * hw + tm * bm, m_end = (img + 1) * hw;
-                if (cfg == 0) wreg_tile<2, 4, 1, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 256, smem);
-                else if (cfg == 1) wreg_tile<2, 2, 2, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 128, smem);
+                // (measurement build: the phases of this workgroup's FIRST tile of the layer, team 0 / slot 0)
+                unsigned long long *tclk = nullptr;
+                if constexpr (CLK != 0) tclk = (a.clk2 && team == 0 && slot == 0 && img == team && t == slot) ? a.clk2 + 8 * li : nullptr;
+                if (cfg == 0) wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk);
+                else if (cfg == 1) wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk);
                 // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
-                else if (cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 256, smem);
-                else if (cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1, NPW>(L, 0, m0, m_end, tn * 128, smem);
-                else wreg_tile<2, 1, 4, 3, 16, 2, NPW>(L, 0, m0, m_end, tn * 64, smem);
+                else if (cfg == 3) wreg_tile<4, 4, 1, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk);
+                else if (cfg == 4) wreg_tile<4, 2, 2, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk);
+                else wreg_tile<2, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk);
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (L.sync && li + 1 < a.n) {
@@ -586,7 +604,9 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
 
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
     if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
-    if (g_tune.npw == 4) hipLaunchKernelGGL(conv_seq_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    if (a.clk2 && g_tune.npw == 4)                        // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
+        hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else if (g_tune.npw == 4) hipLaunchKernelGGL(conv_seq_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv_seq_kernel<2>, dim3(grid), dim3(384), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -728,6 +728,12 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         const bool want_clk = getenv("SMK_SEQ_CLK") != nullptr && !c->graph_mode;
         if (want_clk && !clk_dev) HIPCHK(hipMalloc((void **)&clk_dev, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
         a.clk = want_clk ? clk_dev : nullptr;
+        // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
+        static unsigned long long *clk2_dev = nullptr;
+        const bool want_clk2 = want_clk && !strcmp(getenv("SMK_SEQ_CLK"), "2");
+        if (want_clk2 && !clk2_dev) HIPCHK(hipMalloc((void **)&clk2_dev, sizeof(unsigned long long) * 8 * SEQ_MAX));
+        if (want_clk2) HIPCHK(hipMemsetAsync(clk2_dev, 0, sizeof(unsigned long long) * 8 * SEQ_MAX, s));
+        a.clk2 = want_clk2 ? clk2_dev : nullptr;
         char idn[96];
         snprintf(idn, sizeof(idn), "seq[%s..%s]", c->seq_ids[i0].c_str(), c->seq_ids[i0 + a.n - 1].c_str());
         const double fr = (double)a.n / (double)n;
@@ -742,6 +748,17 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
             for (int i = 0; i < a.n; ++i)
                 fprintf(stderr, "[seq clk]   %-10s cfg %d sync %d  tiles %.2f us  barrier %.2f us\n", c->seq_ids[i0 + i].c_str(),
                         a.L[i].cfg, a.L[i].sync, (h[1 + 2 * i] - h[2 * i]) / 100.0, (h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
+            if (want_clk2) {
+                unsigned long long h2[8 * SEQ_MAX];
+                HIPCHK(hipMemcpy(h2, clk2_dev, sizeof(h2), hipMemcpyDeviceToHost));
+                for (int i = 0; i < a.n; ++i) {
+                    const unsigned long long *t = h2 + 8 * i;
+                    if (!t[0] || !t[6]) continue;
+                    fprintf(stderr, "[seq clk2]  %-10s first tile: operands %.2f | K loop %.2f | wait for the other waves %.2f | accumulators -> LDS %.2f | "
+                            "bias/residual/stores %.2f | end sync %.2f us\n", c->seq_ids[i0 + i].c_str(), (t[1] - t[0]) / 100.0,
+                            (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0, (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0);
+                }
+            }
         }
     }
     c->seq_rec.clear();

@@ -105,6 +105,7 @@ struct SeqArgs {
     unsigned long long *clk;   // optional [2 * SEQ_MAX + 1]: 100 MHz timestamps of (team 0, slot 0): start, then per layer
                                //   (tiles done, barrier passed) -- measurement aid (SMK_SEQ_CLK=1)
     SeqLayer L[SEQ_MAX];
+    unsigned long long *clk2;  // optional [8 * SEQ_MAX] (SMK_SEQ_CLK=2): per layer, the phases of (team 0, slot 0)'s first tile, see wreg_tile
 };
 static_assert(sizeof(SeqArgs) <= 4096, "the layer list travels in the kernel-argument segment");
 
