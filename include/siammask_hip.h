@@ -136,10 +136,15 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
              float *cls_out, float *loc_out, float *mask_out, double *box_out, float *refine_out,
              void *stream);
 
-/* persistent per-XCD convolution sequences (fp16, batch >= 8: the ResNet stages run as conv_seq_kernel launches, one
- * workgroup per CU, image b on XCD b % 8).  grid_out = workgroups per launch (0: the placement check at smk_create
- * failed and the per-layer kernels are used); err_out = device flag (0 ok, 1 placement violated, 2 barrier timeout).
- * Synchronises the device.  Returns non-zero when err != 0. */
+/* persistent per-XCD convolution sequences (fp16, batch 8: ResNet layer2 / layer3 / adjust run as ONE conv_seq_kernel launch,
+ * one workgroup per CU, image b on XCD b % 8).  The kernel needs every workgroup resident at once; when that fails (a
+ * neighbour that holds CUs for more than 0.2 s, a second persistent kernel beside it, an uneven XCD placement) it raises a
+ * flag in host-mapped memory, abandons the remaining layers, and the NEXT entry point called on the context (smk_template /
+ * smk_track / smk_refine / smk_step / smk_seq_status) returns SMK_E_HIP: the results enqueued since then are invalid,
+ * sequences are switched off for the context (per-layer kernels from there on) and the caller re-submits the frame.
+ * smk_seq_status synchronises the device and reports: grid_out = workgroups per launch (0: sequences are off -- the
+ * placement / occupancy check at smk_create failed, or a failure was reported); err_out = last failure (0 none,
+ * 1 placement violated, 2 barrier time-out).  Returns non-zero when a failure has been reported. */
 int smk_seq_status(smk_ctx *ctx, int *grid_out, int *err_out);
 
 /* capture the launch sequences into hipGraphs and replay them (on by default when the
@@ -218,6 +223,26 @@ int smk_op_conv2d(int dtype, int algo, const float *x_dev, int B, int Cin, int H
                   const float *w_host, const float *b_host, int Cout, int k, int stride,
                   int pad, int dil, int relu, const float *res_dev, float *y_dev,
                   void *stream);
+/* smk_op_conv_seq: n <= 36 convolutions as ONE persistent conv_seq_kernel launch (fp16; the kernel that runs ResNet layer2 /
+ * layer3 / adjust at B = 8, experiments/siammask_sharp/resnet.py:64-103,159-165) -- unit parity of every tile configuration,
+ * of the residual path, of independent members (no barrier between them) and of the split team barrier.
+ *   layer i reads the sequence input x (src = -1) or the output of layer src < i; g is the geometry of ITS input (g.B the same
+ *   for all layers; no windows / upsampling); g.res_mode != 0 adds the tensor res_src (-1 = x, j < i = output of layer j,
+ *   same shape as the output) before / after the ReLU; sync != 0 puts a team barrier behind the layer (needed whenever a later
+ *   layer reads what this one or an earlier unsynchronised one wrote); cfg = tile code 0 64x256, 1 64x128, 2 64x64,
+ *   3 128x256, 4 128x128, 5 = measurement variant (64x128, deeper rings), -1 = the engine's choice; kstag = K-loop stagger
+ *   1 / 0, -1 = the engine's choice.  w_host [Cout,Cin,k,k], b_host [Cout] or NULL; y_dev: device f32 NCHW output or NULL.
+ * The launch is repeated `iters` times; *usec_out (optional) = average microseconds of launches 2..iters; clk_us_out
+ * (optional, [2*n]) = per layer, the time (team 0, slot 0) spent in its tiles and in the barrier arrival, of the last launch.
+ * Synchronises the stream (test helper). */
+typedef struct smk_seq_op {
+    smk_conv_geom g;
+    int src, res_src, sync, cfg, kstag;
+    const float *w_host, *b_host;
+    float *y_dev;
+} smk_seq_op;
+int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters, float *usec_out,
+                    float *clk_us_out, void *stream);
 int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, int C,
                     int H, int W, int kh, int kw, float *y_dev, void *stream);
 int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W,

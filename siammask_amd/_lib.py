@@ -26,7 +26,7 @@ SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
     "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status",
     "smk_debug_read", "smk_tune", "smk_tune_get", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
-    "smk_op_maxpool3x3s2", "smk_host_conv2d_ex", "smk_host_plan_conv", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
+    "smk_op_maxpool3x3s2", "smk_op_conv_seq", "smk_host_conv2d_ex", "smk_host_plan_conv", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
 )
 
@@ -35,6 +35,13 @@ class ConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "B", "Cin", "H", "W", "Cout", "k", "stride", "pad", "dil", "relu", "res_mode",
         "win", "ups", "Hl", "Wl", "org_y", "org_x", "pos_mul", "pos_add", "cin_off", "cin_len")]
+
+
+class SeqOp(ctypes.Structure):
+    """smk_seq_op: one layer of an smk_op_conv_seq sequence"""
+    _fields_ = [("g", ConvGeom), ("src", ctypes.c_int), ("res_src", ctypes.c_int), ("sync", ctypes.c_int),
+                ("cfg", ctypes.c_int), ("kstag", ctypes.c_int), ("w_host", ctypes.c_void_p), ("b_host", ctypes.c_void_p),
+                ("y_dev", ctypes.c_void_p)]
 
 
 class SmkError(RuntimeError):
@@ -100,6 +107,7 @@ def lib():
     L.smk_crop_resize.argtypes = [vp, ctypes.c_int64, ci, ci, vp, vp, ci, ci, fp, vp]
     L.smk_paste_mask.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, fp, vp]
     L.smk_paste_labels.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, vp]
+    L.smk_op_conv_seq.argtypes = [ctypes.POINTER(SeqOp), ci, fp, ci, ctypes.POINTER(ctypes.c_float), fp, vp]
     L.smk_bench_conv.argtypes = [ci, ci, gp, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
     for name in SYMBOLS:
         fn = getattr(L, name)

@@ -1,0 +1,196 @@
+// conv_seq.hip -- conv_seq_kernel: a sequence of convolutions (ResNet stages: Bottleneck after Bottleneck,
+// experiments/siammask_sharp/resnet.py:64-103,159-165) as ONE persistent launch.  Tile routine: wreg_tile.inc.
+//
+// Why: at B = 8 the step is ~50 dependent launches of 7-20 us.  Every launch boundary costs 1.5-2 us plus the
+// write-back of what the predecessor left dirty (B / 6 TB/s), the grid fill / drain and each workgroup's cold start,
+// and the next layer re-reads its input from the fabric because it was produced under other XCDs' L2s.  MI355X is
+// eight XCDs with a private 4 MB L2 each -- and the workload is B independent images.  So: image b belongs to XCD
+// b % 8 for the WHOLE sequence.  The 32 workgroups of an XCD (one per CU; a workgroup reads its XCD from
+// HW_REG_XCC_ID and draws a ticket inside the team) share the tiles of their images layer by layer; between dependent
+// layers they meet at a TEAM-LOCAL barrier: plain stores (they stay in the XCD's L2) -> s_waitcnt vmcnt(0) -> one
+// L2-executed atomic per workgroup (ARRIVE) ... sc1 polls (WAIT).  No agent-scope release / acquire, no L2 write-back, no
+// L1 invalidate: the consumers read the handed-over activations with sc1 loads (L2-served), and a layer's 2 MB of
+// activations are L2 hits for the next one.  Weights are read-only (plain loads).  The kernel boundary at the end
+// publishes the results to everybody else.
+//
+// Round 3: the barrier is SPLIT.  A workgroup arrives as soon as its stores have drained, then runs the part of the next
+// layer that does not depend on the previous one -- layer decode, the consumers' first weight fragments (two K tiles),
+// the producers' row / tap decode -- and only then waits (wreg_tile's hoist point), so the weight first touch and the
+// address arithmetic overlap the barrier instead of following it.  The whole layer list (<= 36 layers: layer2 + layer3 +
+// adjust = 33) travels in one kernel-argument segment: one launch per step instead of two.
+//
+// Failure is loud: a barrier that does not complete within 0.2 s (co-residency broken by a neighbour that holds CUs
+// forever, or a second persistent kernel) and a team that received more workgroups than grid / 8 set a flag in device
+// AND host-mapped memory, every workgroup abandons the remaining layers, a later launch that finds the flag set returns
+// at once, and the engine turns the flag into an error at the next entry point (engine.cpp seq_health).
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "smk_kernels.h"
+
+namespace smk {
+
+#include "wreg_tile.inc"
+
+constexpr int SEQ_POLL_TID = 256;              // lane 0 of the first producer wave: it has no loads in flight at the hoist point
+constexpr int SEQ_CLK2_STRIDE = 12;            // u64 per layer of the SMK_SEQ_CLK=2 stamps
+
+__device__ __forceinline__ void seq_raise(const SeqArgs &a, int code) {
+    __hip_atomic_store(a.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.err_host) __hip_atomic_store(a.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ARRIVE: every wave's stores have reached the L2, then one atomic per workgroup
+__device__ __forceinline__ void team_arrive(unsigned *cnt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (threadIdx.x == SEQ_POLL_TID)
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // executes in the XCD's L2
+}
+
+// WAIT, at wreg_tile's hoist point.  The consumer waves carry weight loads in flight there, so the workgroup meets at an
+// LDS-only barrier (__syncthreads() would drain vmcnt).
+struct TeamWait {
+    const SeqArgs *a;
+    unsigned *cnt;
+    unsigned target;            // 0: nothing to wait for
+    int *abort_sh;              // LDS flag: the poller gave up
+    __device__ __forceinline__ bool operator()() const {
+        if (target == 0) return true;
+        if (threadIdx.x == SEQ_POLL_TID) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // sc1 load: L2-served
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 20000000ull) {               // 0.2 s at 100 MHz: never hang the GPU
+                    seq_raise(*a, 2);
+                    *abort_sh = 1;
+                    break;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        return *(volatile int *)abort_sh == 0;
+    }
+};
+
+template <int NPW, int CLK = 0>
+__global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
+    __shared__ int ctl[4];                               // [0] slot, [1] error flag found at entry, [2] abort
+    // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
+    // over the XCDs, starting wherever the previous launch stopped, so blockIdx says nothing); slot = arrival ticket
+    // inside the team.  A one-block-per-CU launch puts gridDim/8 workgroups on every XCD (checked at smk_create).
+    const int nslots = gridDim.x >> 3;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int team = (int)(xcc & 7);
+    unsigned *cnt = a.bar + team * 32;                   // one 128-byte line per team: [0] barrier, [1] exits, [2] tickets
+    if (threadIdx.x == 0) {                              // two independent round trips, issued together
+        const unsigned t = __hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[0] = (int)t;
+        ctl[1] = e;
+        ctl[2] = 0;
+    }
+    __syncthreads();
+    const int slot = ctl[0];
+    if (ctl[1]) return;                                  // an earlier launch failed: do nothing until the host has dealt with it
+    if (slot >= nslots) {                                // more workgroups on this XCD than the census promised
+        if (threadIdx.x == 0) seq_raise(a, 1);
+        return;
+    }
+    unsigned nbar = 0, pending = 0;                      // barriers arrived at; target of the one not yet waited for
+    const bool clk = a.clk && team == 0 && slot == 0 && threadIdx.x == 0;
+    if (clk) a.clk[0] = wall_clock64();
+    bool alive = true;
+    for (int li = 0; li < a.n && alive; ++li) {
+        const SeqLayer &L = a.L[li];
+        const int cfg = L.cfg;
+        const int bn = (cfg == 0 || cfg == 3) ? 256 : ((cfg == 2) ? 64 : 128);
+        const int bm = (cfg == 3 || cfg == 4) ? 128 : 64;
+        const int tilesN = (L.Nst + bn - 1) / bn;
+        const int hw = L.Ho * L.Wo;
+        const int tiles = ((hw + bm - 1) / bm) * tilesN;
+        const int nk = L.Kpad >> 6;
+        // K-loop stagger: the workgroups of a team start at K tiles spread over the whole loop (L.kstag)
+        const int kt0 = L.kstag ? (slot * nk) / nslots : 0;
+        for (int img = team; img < a.B && alive; img += 8)
+            for (int t = slot; t < tiles && alive; t += nslots) {
+                const int tm = t / tilesN, tn = t - tm * tilesN;
+                const int m0 = img * hw + tm * bm, m_end = (img + 1) * hw;
+                // (measurement build: the phases of this workgroup's FIRST tile of the layer, team 0 / slot 0)
+                unsigned long long *tclk = nullptr;
+                if constexpr (CLK != 0)
+                    tclk = (a.clk2 && team == 0 && slot == 0 && img == team && t == slot) ? a.clk2 + SEQ_CLK2_STRIDE * li : nullptr;
+                const TeamWait w{&a, cnt, pending, &ctl[2]};
+                pending = 0;
+                if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
+                else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
+                // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
+                else if (cfg == 3) alive = wreg_tile<4, 4, 1, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
+                else if (cfg == 4) alive = wreg_tile<4, 2, 2, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                // (measurement variant: 64x128 with a 5-deep activation ring and the weight fragments FOUR K tiles ahead)
+                else if (cfg == 5) alive = wreg_tile<2, 2, 2, 5, 16, 4, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else alive = wreg_tile<2, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
+            }
+        if (clk) a.clk[1 + 2 * li] = wall_clock64();
+        if (!alive) break;
+        if (L.sync && li + 1 < a.n) {
+            if (pending) {                               // this workgroup had no tile in the layer: it still has to pass the
+                const TeamWait w{&a, cnt, pending, &ctl[2]};       // previous barrier before it may arrive at the next one
+                pending = 0;
+                if (!w()) break;
+            }
+            team_arrive(cnt);
+            pending = ++nbar * (unsigned)nslots;
+        }
+        if (clk) a.clk[2 + 2 * li] = wall_clock64();
+    }
+    if (!alive || ctl[2]) return;                        // barrier timeout: the host resets the counters (seq_health)
+    // the counters return to zero for the next launch: the LAST workgroup of the team to leave resets them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (prev == (unsigned)nslots - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// census: which XCD does block i run on?  (smk_create checks the i % 8 assumption once per context)
+__global__ void xcc_census_kernel(int *out) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(xcc & 0xf);
+}
+
+int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
+    if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
+    if (a.clk2)                                           // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
+        hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_seq_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+int conv_seq_occupancy() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_seq_kernel<4, 0>, 512, 0) != hipSuccess) return 0;
+    return nb;
+}
+
+int xcc_census(int grid, int *out_host) {
+    int *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(int) * grid) != hipSuccess) return -4;
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(grid), dim3(384), 0, 0, d);
+    hipError_t e = hipMemcpy(out_host, d, sizeof(int) * grid, hipMemcpyDeviceToHost);
+    hipFree(d);
+    return e == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk

@@ -197,6 +197,7 @@ struct smk_ctx {
     int template_B = 0;       // batch of the cached template (0 = none)
     int track_B = 0;          // batch of the last track with SMK_TRACK_MASK
     int last_B = 0, last_S = 0, last_nb = 0;
+    const char *p3_buf = "a";   // arena buffer that holds the layer3 output of the last backbone run (debug read-back)
     bool graph_mode = false;
     hipStream_t cap_stream = nullptr;
     std::map<GraphKey, hipGraphExec_t> graphs;
@@ -215,6 +216,10 @@ struct smk_ctx {
     // persistent per-XCD convolution sequences (conv_seq_kernel)
     unsigned *seq_bar = nullptr;     // [8][32] u32 team counters, zero between launches
     int *seq_err = nullptr;          // device flag written by the kernel (placement / barrier timeout)
+    int *seq_err_host = nullptr;     // the same flag in host-mapped pinned memory: read at every entry point without a sync
+    int *seq_err_hdev = nullptr;     // device address of seq_err_host
+    int seq_fail = 0;                // last failure code taken from the flag (sticky, reported by smk_seq_status)
+    unsigned long long *seq_clk = nullptr, *seq_clk2 = nullptr;   // SMK_SEQ_CLK stamps (measurement aid), per context
     int seq_grid = 0;                // workgroups of a sequence launch (= CUs) when the placement check passed, else 0
     bool seq_on = false;             // run_conv records into seq_rec instead of launching
     // fused frame step: the mask head is handed to the Refine chain launch (chain_mask_kernel) instead of its own launch
@@ -518,6 +523,9 @@ static int build_arena(smk_ctx *c) {
     HIPCHK(hipMemset(c->seq_bar, 0, 8 * 32 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void **)&c->seq_err, sizeof(int)));
     HIPCHK(hipMemset(c->seq_err, 0, sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&c->seq_err_host, 64, hipHostMallocMapped));
+    *c->seq_err_host = 0;
+    HIPCHK(hipHostGetDevicePointer((void **)&c->seq_err_hdev, c->seq_err_host, 0));
     HIPCHK(hipMemset(c->ks_cnt, 0, KS_CNT * sizeof(unsigned)));
     HIPCHK(hipMalloc(&c->dec_scratch, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
     HIPCHK(hipMemset(c->dec_scratch, 0, (size_t)c->maxB * DEC_SCRATCH_PER_STREAM));
@@ -682,12 +690,19 @@ static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt 
 static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     if (!conv_wreg_eligible(p, dtype) || p.groups > 1 || p.pos || p.ups || p.Kpad % 128) return false;
     if (p.kh > 15 || p.kw > 15 || p.stride > 15 || p.pad > 15 || p.dil > 15) return false;
+    // the packed record keeps the geometry in 16-bit fields
+    const int u16[] = {p.Hs, p.Ws, p.Cs, p.cin_off, p.Ci, p.Hl, p.Wl, p.Ho, p.Wo, p.Kpad, p.Nst, p.Cos, p.cout_off, p.res_Cs, p.res_coff};
+    for (int v : u16)
+        if (v < 0 || v > 65535) return false;
+    if (p.org_y < -32768 || p.org_y > 32767 || p.org_x < -32768 || p.org_x > 32767) return false;
     memset(&L, 0, sizeof(L));
     L.in = p.in; L.wgt_frag = p.wgt_frag; L.bias = p.bias; L.res = p.res; L.out = p.out;
     L.in_bytes = p.in_bytes; L.w_bytes = p.w_bytes;
-    L.Hs = p.Hs; L.Ws = p.Ws; L.Cs = p.Cs; L.cin_off = p.cin_off; L.Ci = p.Ci; L.Hl = p.Hl; L.Wl = p.Wl;
-    L.org_y = p.org_y; L.org_x = p.org_x; L.Ho = p.Ho; L.Wo = p.Wo;
-    L.Kpad = p.Kpad; L.Nst = p.Nst; L.Cos = p.Cos; L.cout_off = p.cout_off; L.res_Cs = p.res_Cs; L.res_coff = p.res_coff;
+    L.Hs = (unsigned short)p.Hs; L.Ws = (unsigned short)p.Ws; L.Cs = (unsigned short)p.Cs; L.cin_off = (unsigned short)p.cin_off;
+    L.Ci = (unsigned short)p.Ci; L.Hl = (unsigned short)p.Hl; L.Wl = (unsigned short)p.Wl;
+    L.org_y = (short)p.org_y; L.org_x = (short)p.org_x; L.Ho = (unsigned short)p.Ho; L.Wo = (unsigned short)p.Wo;
+    L.Kpad = (unsigned short)p.Kpad; L.Nst = (unsigned short)p.Nst; L.Cos = (unsigned short)p.Cos;
+    L.cout_off = (unsigned short)p.cout_off; L.res_Cs = (unsigned short)p.res_Cs; L.res_coff = (unsigned short)p.res_coff;
     L.kw_magic = p.kw_magic;
     L.kh = (signed char)p.kh; L.kw = (signed char)p.kw; L.stride = (signed char)p.stride; L.stride_x = (signed char)p.stride_x;
     L.pad = (signed char)p.pad; L.dil = (signed char)p.dil; L.relu = (signed char)p.relu; L.res_mode = (signed char)p.res_mode;
@@ -711,7 +726,30 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
         }
     }
     L.sync = 1;
+    // K-loop stagger (smk_tune "seq_kstag": 0 off, 1 = layers whose weights fit the XCD's L2 beside the activations, 2 = all)
+    L.kstag = (signed char)((g_tune.seq_kstag == 2 || (g_tune.seq_kstag == 1 && (size_t)p.Nst * p.Kpad * 2 <= (3u << 19))) ? 1 : 0);
+    if (g_tune.seq_deep && L.cfg == 1) L.cfg = 5;         // measurement variant (smk_tune "seq_deep")
     return true;
+}
+
+// SMK_SEQ_CLK (measurement aid, eager runs only): print what (team 0, slot 0) stamped
+static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids, const char *idn, const unsigned long long *h,
+                          const unsigned long long *h2) {
+    fprintf(stderr, "[seq clk] %s total %.2f us\n", idn, (h[2 * a.n] - h[0]) / 100.0);
+    for (int i = 0; i < a.n; ++i)
+        fprintf(stderr, "[seq clk]   %-10s cfg %d sync %d kstag %d  tiles %.2f us  arrive %.2f us\n", ids[i].c_str(), a.L[i].cfg,
+                a.L[i].sync, a.L[i].kstag, (h[1 + 2 * i] - h[2 * i]) / 100.0, (h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
+    if (!h2) return;
+    for (int i = 0; i < a.n; ++i) {
+        const unsigned long long *t = h2 + 12 * i;
+        if (!t[0] || !t[6]) continue;
+        const double us = (t[6] - t[0]) / 100.0;
+        fprintf(stderr, "[seq clk2]  %-10s first tile: prologue %.2f | team wait %.2f | first operands %.2f | K loop %.2f | other waves %.2f | "
+                "acc -> LDS %.2f | bias/res/stores %.2f | end sync %.2f us | %.0f MHz\n", ids[i].c_str(),
+                t[7] ? (t[7] - t[0]) / 100.0 : 0.0, 0.0, t[7] ? (t[1] - t[7]) / 100.0 : (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0,
+                (t[3] - t[2]) / 100.0, (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0,
+                us > 0 ? (double)(t[9] - t[8]) / us : 0.0);
+    }
 }
 
 static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
@@ -723,48 +761,62 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.B = B;
         a.bar = c->seq_bar;
         a.err = c->seq_err;
+        a.err_host = c->seq_err_hdev;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
-        static unsigned long long *clk_dev = nullptr;
-        const bool want_clk = getenv("SMK_SEQ_CLK") != nullptr && !c->graph_mode;
-        if (want_clk && !clk_dev) HIPCHK(hipMalloc((void **)&clk_dev, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
-        a.clk = want_clk ? clk_dev : nullptr;
+        const char *ck = getenv("SMK_SEQ_CLK");
+        const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
-        static unsigned long long *clk2_dev = nullptr;
-        const bool want_clk2 = want_clk && !strcmp(getenv("SMK_SEQ_CLK"), "2");
-        if (want_clk2 && !clk2_dev) HIPCHK(hipMalloc((void **)&clk2_dev, sizeof(unsigned long long) * 8 * SEQ_MAX));
-        if (want_clk2) HIPCHK(hipMemsetAsync(clk2_dev, 0, sizeof(unsigned long long) * 8 * SEQ_MAX, s));
-        a.clk2 = want_clk2 ? clk2_dev : nullptr;
+        const bool want_clk2 = want_clk && !strcmp(ck, "2");
+        if (want_clk && !c->seq_clk) HIPCHK(hipMalloc((void **)&c->seq_clk, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
+        if (want_clk2 && !c->seq_clk2) HIPCHK(hipMalloc((void **)&c->seq_clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
+        if (want_clk2) HIPCHK(hipMemsetAsync(c->seq_clk2, 0, sizeof(unsigned long long) * 12 * SEQ_MAX, s));
+        a.clk = want_clk ? c->seq_clk : nullptr;
+        a.clk2 = want_clk2 ? c->seq_clk2 : nullptr;
         char idn[96];
         snprintf(idn, sizeof(idn), "seq[%s..%s]", c->seq_ids[i0].c_str(), c->seq_ids[i0 + a.n - 1].c_str());
         const double fr = (double)a.n / (double)n;
         ProfScope ps(c, s, idn, "conv_seq", c->seq_flop * fr, c->seq_bytes * fr);
         if (launch_conv_seq(a, c->seq_grid, s))
             return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
-        if (want_clk) {                                  // measurement aid: per-layer spans of (team 0, slot 0), eager mode only
-            unsigned long long h[2 * SEQ_MAX + 1];
+        if (want_clk) {                                  // per-layer spans of (team 0, slot 0), eager mode only
+            unsigned long long h[2 * SEQ_MAX + 1], h2[12 * SEQ_MAX];
             HIPCHK(hipStreamSynchronize(s));
-            HIPCHK(hipMemcpy(h, clk_dev, sizeof(h), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[seq clk] %s total %.2f us\n", idn, (h[2 * a.n] - h[0]) / 100.0);
-            for (int i = 0; i < a.n; ++i)
-                fprintf(stderr, "[seq clk]   %-10s cfg %d sync %d  tiles %.2f us  barrier %.2f us\n", c->seq_ids[i0 + i].c_str(),
-                        a.L[i].cfg, a.L[i].sync, (h[1 + 2 * i] - h[2 * i]) / 100.0, (h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
-            if (want_clk2) {
-                unsigned long long h2[8 * SEQ_MAX];
-                HIPCHK(hipMemcpy(h2, clk2_dev, sizeof(h2), hipMemcpyDeviceToHost));
-                for (int i = 0; i < a.n; ++i) {
-                    const unsigned long long *t = h2 + 8 * i;
-                    if (!t[0] || !t[6]) continue;
-                    fprintf(stderr, "[seq clk2]  %-10s first tile: operands %.2f | K loop %.2f | wait for the other waves %.2f | accumulators -> LDS %.2f | "
-                            "bias/residual/stores %.2f | end sync %.2f us\n", c->seq_ids[i0 + i].c_str(), (t[1] - t[0]) / 100.0,
-                            (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0, (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0);
-                }
-            }
+            HIPCHK(hipMemcpy(h, c->seq_clk, sizeof(h), hipMemcpyDeviceToHost));
+            if (want_clk2) HIPCHK(hipMemcpy(h2, c->seq_clk2, sizeof(h2), hipMemcpyDeviceToHost));
+            std::vector<std::string> ids(c->seq_ids.begin() + i0, c->seq_ids.begin() + i0 + a.n);
+            seq_print_clk(a, ids, idn, h, want_clk2 ? h2 : nullptr);
         }
     }
     c->seq_rec.clear();
     c->seq_ids.clear();
     c->seq_flop = c->seq_bytes = 0.0;
     return 0;
+}
+
+// The persistent kernel reports placement violations and barrier time-outs through a flag in host-mapped memory.  Every
+// entry point reads it (a plain host load, no synchronisation): on failure the context stops using sequences, the team
+// counters, the flags and every captured graph (they contain sequence launches) are reset, and the call fails with
+// SMK_E_HIP -- the results of the calls enqueued since the failure are not valid and the caller re-submits them.
+static int seq_health(smk_ctx *c) {
+    if (!c->seq_err_host) return 0;
+    const int e = *(volatile int *)c->seq_err_host;
+    if (!e) return 0;
+    (void)hipDeviceSynchronize();                        // launches that found the flag set returned at once
+    c->seq_fail = e;
+    c->seq_grid = 0;
+    *(volatile int *)c->seq_err_host = 0;
+    (void)hipMemset(c->seq_err, 0, sizeof(int));
+    (void)hipMemset(c->seq_bar, 0, 8 * 32 * sizeof(unsigned));
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    c->graph_used.clear();
+    c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
+    c->track_B = 0;
+    return fail(SMK_E_HIP, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
+                "(the cached template included); persistent sequences are now off for this context (per-layer kernels from here "
+                "on): call template() again and re-submit the frame",
+                e == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out (another kernel held CUs "
+                "for more than 0.2 s, or a second persistent kernel ran beside it)");
 }
 
 static bool seq_wanted(const smk_ctx *c, int B) {
@@ -1013,6 +1065,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : "a") : ((b & 1) ? "b" : "a");
             if (last && st == 2 && cur.p == c->buf.at("a")) oname = "b";
             Act out = act(c, oname, so, so, planes * 4);
+            if (last && st == 2) c->p3_buf = oname;
             ConvOpt o3; o3.relu = 1; o3.res = &res; o3.res_mode = RES_PRE_RELU;
             CHK(run_conv(c, (id + "c3").c_str(), t2, &out, B, o3, s));
             cur = out;
@@ -1284,12 +1337,36 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
     return 0;
 }
 
+// conv_seq_kernel assumes that a one-block-per-CU launch puts the same number of blocks on every XCD (the dispatcher
+// deals consecutive blocks round-robin over the XCDs -- observed, not a HIP guarantee) and that one workgroup of it
+// (139 KB of LDS, 512 threads) is resident per CU: checked once per context with a census launch and the runtime's
+// occupancy answer for THAT kernel; if either fails the per-launch kernels are used instead.  Returns the grid or 0.
+static int seq_grid_for(int ncu) {
+    if (ncu < 8 || ncu % 8 != 0 || ncu > 1024) return 0;
+    std::vector<int> x(ncu, -1);
+    const int crc = xcc_census(ncu, x.data());
+    bool ok = crc == 0;
+    int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; ok && i < ncu; ++i) {
+        if (x[i] < 0 || x[i] > 7) ok = false;
+        else per[x[i]]++;
+    }
+    for (int q = 0; ok && q < 8; ++q) ok = per[q] == ncu / 8;
+    const int occ = conv_seq_occupancy();
+    if (ok && occ < 1) ok = false;
+    if (!ok && getenv("SMK_DEBUG"))
+        fprintf(stderr, "[siammask_hip] XCD placement check failed (rc %d, %d CUs, per XCD %d %d %d %d %d %d %d %d, occupancy %d): "
+                "persistent sequences off\n", crc, ncu, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7], occ);
+    return ok ? ncu : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 2; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box
+int smk_version(void) { return (1 << 16) | 3; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
+                                                  // sequence failures reported at the next entry point
 
 const char *smk_last_error(void) { return g_err.c_str(); }
 
@@ -1314,28 +1391,7 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     int rc = build_arena(c.get());
     if (rc) return rc;
     if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
-    {
-        // conv_seq_kernel assumes that a one-block-per-CU launch puts the same number of blocks on every XCD (the
-        // dispatcher deals consecutive blocks round-robin over the XCDs -- observed, not a HIP guarantee): check it once
-        // per context; if it does not hold the per-launch kernels are used instead
-        const int ncu = prop.multiProcessorCount;
-        c->seq_grid = 0;
-        if (ncu >= 8 && ncu % 8 == 0 && ncu <= 1024) {
-            std::vector<int> x(ncu, -1);
-            const int crc = xcc_census(ncu, x.data());
-            bool ok = crc == 0;
-            int per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; ok && i < ncu; ++i) {
-                if (x[i] < 0 || x[i] > 7) ok = false;
-                else per[x[i]]++;
-            }
-            for (int q = 0; ok && q < 8; ++q) ok = per[q] == ncu / 8;
-            if (ok) c->seq_grid = ncu;
-            else if (getenv("SMK_DEBUG"))
-                fprintf(stderr, "[siammask_hip] XCD placement check failed (rc %d, %d CUs, per XCD %d %d %d %d %d %d %d %d): "
-                        "persistent sequences off\n", crc, ncu, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7]);
-        }
-    }
+    c->seq_grid = seq_grid_for(prop.multiProcessorCount);
     for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
     c->ev_pool.resize(64);
     for (auto &e : c->ev_pool) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1366,6 +1422,9 @@ int smk_destroy(smk_ctx *c) {
     if (c->ks_cnt) hipFree(c->ks_cnt);
     if (c->seq_bar) hipFree(c->seq_bar);
     if (c->seq_err) hipFree(c->seq_err);
+    if (c->seq_err_host) hipHostFree(c->seq_err_host);
+    if (c->seq_clk) hipFree(c->seq_clk);
+    if (c->seq_clk2) hipFree(c->seq_clk2);
     if (c->window_dev) hipFree(c->window_dev);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
@@ -1529,12 +1588,13 @@ int smk_seq_status(smk_ctx *c, int *grid, int *err) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    int e = 0;
-    HIPCHK(hipMemcpy(&e, c->seq_err, sizeof(int), hipMemcpyDeviceToHost));
+    const int rc = seq_health(c);                        // picks up a failure of the work that has just drained
     if (grid) *grid = c->seq_grid;
-    if (err) *err = e;
-    if (e) return fail(SMK_E_STATE, "conv_seq_kernel reported %s", e == 1 ? "an uneven distribution of workgroups over the XCDs"
-                                                                         : "a team-barrier timeout");
+    if (err) *err = c->seq_fail;
+    if (rc) return rc;
+    if (c->seq_fail)
+        return fail(SMK_E_STATE, "conv_seq_kernel reported %s earlier; persistent sequences are off for this context",
+                    c->seq_fail == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out");
     return 0;
 }
 
@@ -1549,6 +1609,7 @@ int smk_template(smk_ctx *c, const float *z, int B, void *stream) {
     if (!c->finalized) return fail(SMK_E_STATE, "smk_template: weights not finalized");
     if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_template: batch %d not in [1,%d]", B, c->maxB);
     HIPCHK(hipSetDevice(c->device));
+    CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
     GraphKey key{0, B, 0, {z}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_template(c, z, B, st); });
@@ -1570,6 +1631,7 @@ int smk_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *l
     if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) && !mask)
         return fail(SMK_E_ARG, "smk_track: mask_out is NULL");
     HIPCHK(hipSetDevice(c->device));
+    CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
     GraphKey key{1, B, flags, {x, cls, loc, mask}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_track(c, x, B, flags, cls, loc, mask, st); });
@@ -1584,6 +1646,7 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
     if (c->track_B == 0) return fail(SMK_E_STATE, "smk_refine: needs a preceding smk_track with SMK_TRACK_MASK");
     if (B != c->track_B) return fail(SMK_E_ARG, "smk_refine: batch %d != tracked batch %d", B, c->track_B);
     HIPCHK(hipSetDevice(c->device));
+    CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
     if (!on_device) {
         for (int i = 0; i < 2 * B; ++i)
@@ -1609,6 +1672,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
     else if (!strcmp(key, "ablate")) g_tune.ablate = value & 7;
+    else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
+    else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
@@ -1637,7 +1702,8 @@ int smk_tune_get(const char *key, int *value) {
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
-        {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall},
+        {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
+        {"seq_deep", &g_tune.seq_deep},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch},
@@ -1756,6 +1822,7 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
     if ((flags & SMK_TRACK_MASK) && c->variant == SMK_VARIANT_RPN) return fail(SMK_E_ARG, "smk_step: rpn has no mask branch");
     if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) && !mask) return fail(SMK_E_ARG, "smk_step: mask_out is NULL");
     HIPCHK(hipSetDevice(c->device));
+    CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
     int64_t pk, wi;
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
@@ -1796,7 +1863,7 @@ int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int
     struct E { const char *n, *b; int h, w, cs, cn; };
     const E tab[] = {
         {"p0", "p0", s0, s0, 64, 64}, {"p1", "p1", s1, s1, 256, 256}, {"p2", "p2", s2, s2, 512, 512},
-        {"search", "search", 31, 31, 256, 256}, {"zf", "zf", 7, 7, 256, 256},
+        {"p3", c->p3_buf, s2, s2, 1024, 1024}, {"search", "search", 31, 31, 256, 256}, {"zf", "zf", 7, 7, 256, 256},
         {"zk", "zk", 5, 5, 256 * nbt, 256 * nbt}, {"xs", "xs", 29, 29, 256 * nbt, 256 * nbt},
         {"corr", "corr", 25, 25, 256 * nbt, 256 * nbt}, {"head0", "head0", 25, 25, 256 * nbt, 256 * nbt},
     };
@@ -1956,6 +2023,136 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0};
         if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
     }
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// A sequence of convolutions through conv_seq_kernel on caller-described layers (unit parity of the persistent kernel:
+// every tile configuration, residual and independent-member cases; micro-benchmarks of its K loop).  fp16 only.
+int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters, float *usec_out, float *clk_us_out,
+                    void *stream) {
+    if (!ops || !x_dev || n < 1 || n > SEQ_MAX || iters < 1) return fail(SMK_E_ARG, "smk_op_conv_seq: bad argument (1..%d layers)", SEQ_MAX);
+    hipStream_t s = (hipStream_t)stream;
+    const int dtype = DT_F16;
+    const size_t es = esize(dtype);
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    const int grid = seq_grid_for(prop.multiProcessorCount);
+    if (!grid) return fail(SMK_E_STATE, "smk_op_conv_seq: the XCD placement / occupancy check failed on this device");
+    TmpBufs tmp;
+    const int B = ops[0].g.B;
+    Act xin;
+    xin.H = ops[0].g.H; xin.W = ops[0].g.W; xin.C = rup(ops[0].g.Cin, 8);
+    CHK(tmp.alloc(&xin.p, (size_t)B * xin.H * xin.W * xin.C * es));
+    CvtInParams ci{x_dev, xin.p, B, ops[0].g.Cin, xin.H, xin.W, xin.C, 0};
+    if (launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    smk_ctx fake;
+    fake.dtype = dtype;
+    fake.device = dev;
+    std::vector<Act> outs(n);
+    std::vector<int> couts(n);
+    std::vector<PackedConv> packs(n);
+    SeqArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n; a.B = B;
+    std::vector<std::string> ids;
+    for (int i = 0; i < n; ++i) {
+        const smk_seq_op &op = ops[i];
+        if (!op.w_host) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d has no weights", i);
+        if (op.src >= i || op.res_src >= i) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d reads a later layer", i);
+        if (op.g.B != B || op.g.win || op.g.ups) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d: one batch, no windows", i);
+        const Act &in = op.src < 0 ? xin : outs[op.src];
+        const int cin_have = op.src < 0 ? ops[0].g.Cin : couts[op.src];
+        if (op.g.H != in.H || op.g.W != in.W || op.g.Cin != cin_have)
+            return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d geometry does not match its source", i);
+        PackedConv pc; Act gin; ConvOpt o; int Ho, Wo;
+        CHK(fill_geom(&op.g, pc, gin, o, Ho, Wo));
+        int same = -1;                                    // a layer that names the SAME host weights re-uses the device copy
+        for (int j = 0; j < i && same < 0; ++j)           // (micro-benchmarks: L2-warm weights)
+            if (ops[j].w_host == op.w_host && ops[j].b_host == op.b_host && ops[j].g.Cout == op.g.Cout &&
+                ops[j].g.Cin == op.g.Cin && ops[j].g.k == op.g.k && ops[j].g.cin_len == op.g.cin_len) same = j;
+        if (same >= 0) {
+            pc.w = packs[same].w; pc.bias = packs[same].bias; pc.w_frag = packs[same].w_frag;
+        } else {
+            std::vector<float> rows, bias;
+            pack_host(&op.g, pc, op.w_host, op.b_host, rows, bias);
+            CHK(upload_packed(pc, rows, bias, dtype));
+            tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
+            if (pc.w_frag) tmp.v.push_back(pc.w_frag);
+        }
+        packs[i] = pc;
+        outs[i].H = Ho; outs[i].W = Wo; outs[i].C = rup(op.g.Cout, 8);
+        couts[i] = op.g.Cout;
+        CHK(tmp.alloc(&outs[i].p, (size_t)B * Ho * Wo * outs[i].C * es));
+        Act res;
+        if (op.g.res_mode) {
+            if (op.res_src < -1) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d wants a residual without a source", i);
+            res = op.res_src < 0 ? xin : outs[op.res_src];
+            if (res.H != Ho || res.W != Wo || res.C != outs[i].C)
+                return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d: residual shape differs from the output", i);
+            o.res = &res; o.res_mode = op.g.res_mode;
+        }
+        ConvParams p;
+        CHK(conv_params(&fake, pc, in, &outs[i], B, o, p));
+        SeqLayer L;
+        if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
+        if (op.cfg >= 0) {
+            if (op.cfg > 5) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..5");
+            L.cfg = (signed char)op.cfg;
+        }
+        if (op.kstag >= 0) L.kstag = (signed char)(op.kstag != 0);
+        L.sync = (signed char)(op.sync != 0);
+        a.L[i] = L;
+        char nm[16];
+        snprintf(nm, sizeof(nm), "op%d", i);
+        ids.push_back(nm);
+    }
+    unsigned *bar = nullptr;
+    int *err = nullptr;
+    unsigned long long *clk = nullptr, *clk2 = nullptr;
+    CHK(tmp.alloc((void **)&bar, 8 * 32 * sizeof(unsigned)));
+    CHK(tmp.alloc((void **)&err, sizeof(int)));
+    CHK(tmp.alloc((void **)&clk, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
+    const char *ck = getenv("SMK_SEQ_CLK");
+    const bool want2 = ck && !strcmp(ck, "2");
+    if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
+    a.bar = bar; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    if (launch_conv_seq(a, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIPCHK(hipEventRecord(e0, s));
+    for (int it = 1; it < iters; ++it)
+        if (launch_conv_seq(a, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    if (iters > 1) HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (usec_out) *usec_out = iters > 1 ? ms * 1000.f / (iters - 1) : 0.f;
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) return fail(SMK_E_HIP, "conv_seq_kernel reported %s", e == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out");
+    {
+        unsigned long long h[2 * SEQ_MAX + 1], h2[12 * SEQ_MAX];
+        HIPCHK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+        if (clk_us_out)
+            for (int i = 0; i < n; ++i) {
+                clk_us_out[2 * i] = (float)((h[1 + 2 * i] - h[2 * i]) / 100.0);
+                clk_us_out[2 * i + 1] = (float)((h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
+            }
+        if (ck) {
+            if (want2) HIPCHK(hipMemcpy(h2, clk2, sizeof(h2), hipMemcpyDeviceToHost));
+            seq_print_clk(a, ids, "smk_op_conv_seq", h, want2 ? h2 : nullptr);
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (ops[i].y_dev) {
+            CvtOutParams co{outs[i].p, ops[i].y_dev, B, couts[i], outs[i].H, outs[i].W, outs[i].C, 0};
+            if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
+        }
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -79,7 +79,8 @@ struct ConvBatch {
 };
 
 // one layer of a persistent convolution sequence (conv_seq_kernel): the ConvParams fields conv_wreg's tile routine
-// reads, under the same names, packed so that a whole ResNet stage travels in the 4 KB kernel-argument segment
+// reads, under the same names, packed (104 bytes) so that layer2 + layer3 + adjust (33 convolutions) travel in ONE
+// 4 KB kernel-argument segment
 struct SeqLayer {
     const void *in;        // NHWC f16 [B][Hs][Ws][Cs]
     const void *wgt_frag;  // fragment-order weights
@@ -87,25 +88,31 @@ struct SeqLayer {
     const void *res;       // residual (NHWC f16) or nullptr
     void *out;             // NHWC f16
     unsigned in_bytes, w_bytes;
-    int Hs, Ws, Cs, cin_off, Ci, Hl, Wl, org_y, org_x, Ho, Wo;
-    int Kpad, Nst, Cos, cout_off, res_Cs, res_coff, kw_magic;
+    int kw_magic;
+    unsigned short Hs, Ws, Cs, cin_off, Ci, Hl, Wl, Ho, Wo, Kpad, Nst, Cos, cout_off, res_Cs, res_coff;
+    short org_y, org_x;
     signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
-    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128
+    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128;
+                           //   measurement variants: 5 = 64x128 with a 5-deep ring and weights 4 K tiles ahead
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
     signed char a_stage;   // see ConvParams::a_stage
+    signed char kstag;     // 1: every workgroup starts its K loop at another K tile (see wreg_tile kt0)
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
 };
-constexpr int SEQ_MAX = 24;
+static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
+constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
     unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits, [2] tickets
-    int *err;              // device flag: 1 = an XCD received more workgroups than grid / 8, 2 = barrier timeout
+    int *err;              // device flag: 1 = an XCD received more workgroups than grid / 8, 2 = barrier timeout; a launch that
+                           //   finds it set returns at once
+    int *err_host;         // the same flag in host-mapped pinned memory (the engine checks it at every entry, no sync)
     unsigned long long *clk;   // optional [2 * SEQ_MAX + 1]: 100 MHz timestamps of (team 0, slot 0): start, then per layer
                                //   (tiles done, barrier passed) -- measurement aid (SMK_SEQ_CLK=1)
-    SeqLayer L[SEQ_MAX];
     unsigned long long *clk2;  // optional [8 * SEQ_MAX] (SMK_SEQ_CLK=2): per layer, the phases of (team 0, slot 0)'s first tile, see wreg_tile
+    SeqLayer L[SEQ_MAX];
 };
 static_assert(sizeof(SeqArgs) <= 4096, "the layer list travels in the kernel-argument segment");
 
@@ -140,6 +147,9 @@ struct Tuning {
     int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 2;          // sequences: 128-row tiles for layers that would otherwise need several 64-row rounds per image
                                // (1: short-K layers only -- the rule with two producer waves; 2: all, measured -1.7 % with four)
+    int seq_kstag = 0;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
+                               // weights fit the L2, 2 all)
+    int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
     int wreg_policy = 1;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer
                                // waves), 1 = the rule fitted with four (wreg_choice)
@@ -265,6 +275,8 @@ bool conv_wreg_eligible(const ConvParams &p, int dtype);
 int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stream);
 // a sequence of convolutions as one persistent launch of `grid` workgroups (one per CU, a multiple of 8)
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream);
+// resident workgroups per CU the runtime promises for conv_seq_kernel (0: it cannot run; smk_create's gate)
+int conv_seq_occupancy();
 // XCD id of every block of a `grid`-block launch -> host array (synchronous; smk_create's placement check)
 int xcc_census(int grid, int *out_host);
 // the sequential tail of Refine (h2, post0, h1, post1, h0, post2) as one launch, fp16 only (refine_chain.hip)

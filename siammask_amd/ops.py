@@ -70,6 +70,60 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=
     return y
 
 
+SEQ_CFG = {None: -1, (64, 256): 0, (64, 128): 1, (64, 64): 2, (128, 256): 3, (128, 128): 4, "deep": 5}
+
+
+def conv_seq(x, layers, iters=1, want_outputs=True):
+    """smk_op_conv_seq: a list of convolutions as ONE persistent conv_seq_kernel launch (fp16).
+
+    x: [B,C,H,W] float32 CUDA tensor.  layers: dicts with w [Cout,Cin,k,k] (numpy), optional b, stride, pad, dil, relu,
+    src (-1 = x, j = output of layer j; default: the previous layer), res (source index of the residual, -1 = x) with
+    res_mode 1 (before the ReLU) / 2 (after), sync (default True), tile ((bm, bn), "deep" or None), kstag (-1 engine's choice).
+    Returns (outputs [list of float32 NCHW tensors], usec per launch, per-layer (tiles_us, arrive_us) array)."""
+    _chk_cuda(x)
+    x = x.contiguous().float()
+    B = x.shape[0]
+    n = len(layers)
+    arr = (_lib.SeqOp * n)()
+    keep = []
+    shapes = [tuple(x.shape[1:])]          # shape of x, then of every output
+    outs = []
+    for i, l in enumerate(layers):
+        w = np.ascontiguousarray(l["w"], dtype=np.float32)
+        b = None if l.get("b") is None else np.ascontiguousarray(l["b"], dtype=np.float32)
+        keep += [w, b]
+        src = l.get("src", i - 1)
+        cin, H, W = shapes[src + 1]
+        k, stride, pad, dil = w.shape[2], l.get("stride", 1), l.get("pad", 0), l.get("dil", 1)
+        g = arr[i].g
+        g.B, g.Cin, g.H, g.W = B, cin, H, W
+        g.Cout, g.k, g.stride, g.pad, g.dil = w.shape[0], k, stride, pad, dil
+        g.relu = int(bool(l.get("relu", False)))
+        g.res_mode = l.get("res_mode", 1) if "res" in l else 0
+        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        shapes.append((w.shape[0], Ho, Wo))
+        arr[i].src = src
+        arr[i].res_src = l.get("res", -2)
+        arr[i].sync = int(bool(l.get("sync", True)))
+        arr[i].cfg = SEQ_CFG[l.get("tile")]
+        arr[i].kstag = l.get("kstag", -1)
+        arr[i].w_host = w.ctypes.data
+        arr[i].b_host = b.ctypes.data if b is not None else None
+        if want_outputs:
+            y = torch.empty((B, w.shape[0], Ho, Wo), dtype=torch.float32, device=x.device)
+            outs.append(y)
+            arr[i].y_dev = y.data_ptr()
+        else:
+            arr[i].y_dev = None
+    us = ctypes.c_float(0.0)
+    clk = np.zeros(2 * n, dtype=np.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().smk_op_conv_seq(arr, n, x.data_ptr(), iters, ctypes.byref(us),
+                                              clk.ctypes.data_as(ctypes.c_void_p), _lib.current_stream_ptr()))
+    return outs, us.value, clk.reshape(n, 2)
+
+
 def dw_xcorr(x, k, dtype="f32"):
     _chk_cuda(x, k)
     x, k = x.contiguous().float(), k.contiguous().float()

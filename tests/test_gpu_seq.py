@@ -1,0 +1,229 @@
+"""GPU parity of conv_seq_kernel -- the persistent per-XCD convolution sequence that runs ResNet layer2 / layer3 /
+adjust at B = 8 (experiments/siammask_sharp/resnet.py:64-103,159-165) -- through its own C-ABI entry smk_op_conv_seq.
+
+Every layer of every sequence is held to the per-op gate of tests/test_gpu_ops.py (fp16: 2e-3 of max|ref|, exact sums in
+the oracle) ONE LAYER DEEP: the reference of layer i is the oracle convolution of the tensors the device itself handed to
+layer i (its fp16 outputs are exactly representable), so an error cannot hide behind the error of an earlier layer.
+Covered: the five workgroup-tile configurations (+ the deep-ring measurement variant), residual before the ReLU,
+independent members without a barrier between them, several images per team, several tiles per workgroup, the K-loop
+stagger, and the failure path (a sequence that cannot complete raises instead of returning garbage)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-3
+TILES = [(64, 256), (64, 128), (64, 64), (128, 256), (128, 128), "deep"]
+
+
+def _ops():
+    from siammask_amd import ops
+    return ops
+
+
+def _q(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float64)
+
+
+def _w(rng, cout, cin, k):
+    return (rng.uniform(-1, 1, size=(cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+
+
+def _check(x, layers, outs, what):
+    """layer-by-layer: oracle conv of the DEVICE's own inputs of that layer"""
+    got = [o.cpu().numpy().astype(np.float64) for o in outs]
+    srcs = [_q(x)] + got
+    errs = {}
+    for i, l in enumerate(layers):
+        a = srcs[l.get("src", i - 1) + 1]
+        ref = O.conv2d(a, _q(l["w"]), None if l.get("b") is None else l["b"].astype(np.float64),
+                       l.get("stride", 1), l.get("pad", 0), l.get("dil", 1))
+        if "res" in l and l.get("res_mode", 1) == 1:
+            ref = ref + srcs[l["res"] + 1]
+        if l.get("relu"):
+            ref = np.maximum(ref, 0)
+        if "res" in l and l.get("res_mode", 1) == 2:
+            ref = ref + srcs[l["res"] + 1]
+        errs[i] = rel_err(got[i], ref)
+    bad = {i: e for i, e in errs.items() if not e <= TOL}
+    assert not bad, "%s: layers %s over %.0e (all %s)" % (what, bad, TOL, errs)
+    return errs
+
+
+def _bottleneck(rng, cin, planes, k2=3, dil=2, tile=None, kstag=-1):
+    """conv1 1x1 -> conv2 3x3 (dilated, same size) -> conv3 1x1 + input, ReLU: resnet.py:80-103"""
+    return [
+        dict(w=_w(rng, planes, cin, 1), b=rng.uniform(-1, 1, planes).astype(np.float32), relu=True, tile=tile, kstag=kstag),
+        dict(w=_w(rng, planes, planes, k2), b=rng.uniform(-1, 1, planes).astype(np.float32), pad=dil * (k2 // 2), dil=dil,
+             relu=True, tile=tile, kstag=kstag),
+        dict(w=_w(rng, cin, planes, 1), b=rng.uniform(-1, 1, cin).astype(np.float32), relu=True, res=-1, res_mode=1,
+             tile=tile, kstag=kstag),
+    ]
+
+
+@pytest.mark.parametrize("kstag", [0, 1])
+@pytest.mark.parametrize("tile", TILES)
+def test_conv_seq_every_tile_configuration(tile, kstag):
+    """a Bottleneck (1x1 -> dilated 3x3 -> 1x1 + residual) forced onto each workgroup tile; B = 3 (three teams work, five
+    idle through every barrier), 23x23 = 529 rows per image: ragged last tile for 64- and 128-row tiles"""
+    ops = _ops()
+    rng = np.random.default_rng(11 + TILES.index(tile) + 100 * kstag)
+    x = rng.uniform(-1, 1, size=(3, 256, 23, 23)).astype(np.float32)
+    layers = _bottleneck(rng, 256, 128, tile=tile, kstag=kstag)
+    outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers)
+    _check(x, layers, outs, "tile %s kstag %d" % (tile, kstag))
+
+
+def test_conv_seq_independent_members_and_strided_shortcut():
+    """layer2.0 / layer3.0 shape of the engine's list: the shortcut convolution (3x3 stride 2 pad 0) and conv1 both read the
+    block input and carry NO barrier between them; conv3 adds the shortcut's output; a second block follows"""
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    cin, planes = 128, 64
+    x = rng.uniform(-1, 1, size=(2, cin, 31, 31)).astype(np.float32)
+    layers = [
+        dict(w=_w(rng, planes * 4, cin, 3), b=rng.uniform(-1, 1, planes * 4).astype(np.float32), stride=2, src=-1, sync=False),
+        dict(w=_w(rng, planes, cin, 1), relu=True, src=-1),
+        dict(w=_w(rng, planes, planes, 3), relu=True, stride=2, src=1),
+        dict(w=_w(rng, planes * 4, planes, 1), relu=True, src=2, res=0, res_mode=1),
+    ]
+    blk = _bottleneck(rng, planes * 4, planes, dil=1)      # a second block on the first one's output
+    blk[2]["res"] = 3
+    layers += blk
+    outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers)
+    _check(x, layers, outs, "independent members")
+
+
+def test_conv_seq_two_images_per_team_and_two_rounds_of_tiles():
+    """B = 10: teams 0 and 1 own two images each (b, b + 8); 47x47 = 2209 rows per image = 35 tiles of 64 rows x 2 column
+    tiles = 70 tiles for the 32 workgroups of a team (three rounds, the last one partial)"""
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, size=(10, 64, 47, 47)).astype(np.float32)
+    layers = [
+        dict(w=_w(rng, 128, 64, 1), b=rng.uniform(-1, 1, 128).astype(np.float32), relu=True, tile=(64, 64)),
+        dict(w=_w(rng, 64, 128, 3), pad=1, relu=True, tile=(64, 64)),
+        dict(w=_w(rng, 64, 64, 1), relu=True, res=-1, res_mode=2, tile=(128, 128)),
+    ]
+    outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers)
+    _check(x, layers, outs, "B=10")
+
+
+def test_conv_seq_real_layer3_block_engine_choice():
+    """the real shapes of a layer3 identity Bottleneck at the bench's batch (B = 8, 31x31, 1024 -> 256 -> 256 d2 -> 1024 +
+    residual) and of layer3.0's long-K shortcut (3x3 512 -> 1024), with the tile and stagger rule the engine uses"""
+    ops = _ops()
+    rng = np.random.default_rng(41)
+    x = rng.uniform(-1, 1, size=(8, 1024, 31, 31)).astype(np.float32)
+    layers = _bottleneck(rng, 1024, 256)
+    outs, us, clk = ops.conv_seq(torch.from_numpy(x).cuda(), layers, iters=3)
+    _check(x, layers, outs, "layer3 block")
+    assert us > 0 and clk.shape == (3, 2)
+    x2 = rng.uniform(-1, 1, size=(8, 512, 31, 31)).astype(np.float32)
+    l2 = [dict(w=_w(rng, 1024, 512, 3), b=rng.uniform(-1, 1, 1024).astype(np.float32), pad=1)]
+    outs, _, _ = ops.conv_seq(torch.from_numpy(x2).cuda(), l2)
+    _check(x2, l2, outs, "layer3.0 shortcut")
+
+
+def test_conv_seq_repeated_launches_leave_the_counters_clean():
+    """the team counters reset themselves: 20 launches in a row (iters) and a second call give the same bits"""
+    ops = _ops()
+    rng = np.random.default_rng(51)
+    x = rng.uniform(-1, 1, size=(8, 128, 15, 15)).astype(np.float32)
+    layers = _bottleneck(rng, 128, 64, dil=1)
+    xd = torch.from_numpy(x).cuda()
+    a, _, _ = ops.conv_seq(xd, layers, iters=20)
+    b, _, _ = ops.conv_seq(xd, layers, iters=1)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    _check(x, layers, a, "repeated")
+
+
+# ---- failure must be loud and safe (the kernel needs all 256 workgroups resident at once) ---------------------------------
+def _model(B):
+    from siammask_amd import synth
+    from siammask_amd.custom import build
+    m = build("sharp", dtype="f16", graph=True, max_batch=B)
+    m.load_state_dict(synth.torch_state_dict("sharp", "synthetic_damped"))
+    return m.eval().cuda()
+
+
+def _step_inputs(B, stream0):
+    from siammask_amd import synth
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=stream0)).cuda()
+    x = torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=stream0)).cuda()
+    twh = torch.tensor([[60.0, 80.0]] * B, dtype=torch.float64).cuda()
+    return z, x, twh
+
+
+def _safe_step(m, z, x, twh, want, what):
+    """one frame step that must be EITHER correct OR raise; after a raise the context has fallen back to the per-layer kernels
+    and the re-submitted template + frame must be correct.  Returns True when the failure path was taken."""
+    from siammask_amd import _lib
+    raised = False
+    try:
+        out = {k: v.clone() for k, v in m.track_step(x, twh, refine=True).items() if v is not None}
+        torch.cuda.synchronize()
+        grid, err = m.seq_status()                    # raises when the work that has just drained reported a failure
+    except _lib.SmkError as e:
+        raised = True
+        assert "conv_seq_kernel reported" in str(e), e
+        m.template(z)                                 # the failure report invalidates the cached template as well
+        out = {k: v.clone() for k, v in m.track_step(x, twh, refine=True).items() if v is not None}
+        torch.cuda.synchronize()
+        try:
+            m.seq_status()
+        except _lib.SmkError as e2:                   # sticky report of the earlier failure: sequences are off now
+            assert "persistent sequences are off" in str(e2), e2
+    for k in ("cls", "loc", "mask", "refine"):
+        e = rel_err(out[k].cpu().numpy(), want[k])
+        assert e <= 5e-3, "%s: %s differs from the solo run by %.2e (failure path taken: %s)" % (what, k, e, raised)
+    return raised
+
+
+def test_two_contexts_on_two_streams_stay_correct_or_raise():
+    """two contexts stepping concurrently on two streams: each launch of conv_seq_kernel needs every CU, so the two can
+    starve each other of co-residency.  Whatever the dispatcher does, every step is either correct or reported."""
+    B = 8
+    z, x, twh = _step_inputs(B, 500)
+    ref = _model(B)
+    ref.template(z)
+    want = {k: v.cpu().numpy() for k, v in ref.track_step(x, twh, refine=True).items() if v is not None}
+    torch.cuda.synchronize()
+    del ref
+    ms = [_model(B), _model(B)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for m, st in zip(ms, streams):
+        with torch.cuda.stream(st):
+            m.template(z)
+    torch.cuda.synchronize()
+    raised = 0
+    for it in range(6):
+        for m, st in zip(ms, streams):
+            with torch.cuda.stream(st):
+                raised += _safe_step(m, z, x, twh, want, "two contexts, round %d" % it)
+    print("two contexts: failure path taken %d times of 12" % raised)
+
+
+def test_side_stream_work_during_a_step_stays_correct_or_raises():
+    """a side stream keeps the CUs busy with large GEMMs (what an RCCL gather or another model would do) while the fused
+    B = 8 step with its persistent launch runs: correct, or reported and correct after the fall-back"""
+    B = 8
+    z, x, twh = _step_inputs(B, 520)
+    m = _model(B)
+    m.template(z)
+    want = {k: v.cpu().numpy() for k, v in m.track_step(x, twh, refine=True).items() if v is not None}
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.float16)
+    raised = 0
+    for it in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                a = (a @ a).clamp_(-1, 1)
+        raised += _safe_step(m, z, x, twh, want, "side stream, round %d" % it)
+    torch.cuda.synchronize()
+    print("side stream: failure path taken %d times of 4" % raised)
