@@ -298,14 +298,36 @@ def cpu_model_string():
     return platform.processor() or "unknown"
 
 
+def cpu_reference_model():
+    """The reference's own Custom (experiments/siammask_sharp/custom.py) from oracle/_ref -- the reference in compiled
+    form, built by oracle/build_ref.py where /root/reference exists and shipped like the built .so -- loaded through its
+    own utils/load_helper.load_pretrain; None when oracle/_ref is not there (then the torch port is timed)."""
+    ref = os.path.join(REPO, "oracle", "_ref", "reference")
+    if not os.path.isfile(os.path.join(ref, "tools", "test.pyc")):
+        return None
+    os.environ["SIAMMASK_REFERENCE"] = ref
+    try:
+        import logging
+        logging.disable(logging.INFO)                  # load_pretrain logs every key
+        from oracle.make_golden import build_reference
+        return build_reference("sharp", synth.state_dict("sharp", "synthetic_damped"))
+    except Exception as e:  # noqa: BLE001 -- a broken oracle/_ref must not take the bench line down
+        sys.stderr.write("bench.py: oracle/_ref present but not usable (%s); timing the port\n" % e)
+        return None
+
+
 def cpu_baseline(budget_s=10.0):
-    """CPU port of the reference op sequence (fp32, torch CPU ops on the host cores, oracle/torch_port.py pinned to the
-    reference's own outputs): sharp track_mask + track_refine at B=1 and at B=8 ("CPU reference timing
-    beside it ... at B=1 and B=8").  A short scan picks the best thread count (ATen's convolutions stop scaling long
+    """The reference on the host cores beside the GPU number ("CPU reference timing beside it ... at B=1 and
+    B=8"): sharp track_mask + track_refine, fp32.  kind "reference" = the reference's own Custom modules (oracle/_ref);
+    kind "port" = oracle/torch_port.py, the same ATen op sequence as functional calls, pinned to the reference's outputs
+    (used where oracle/_ref is absent).  A short scan picks the best thread count (ATen's convolutions stop scaling long
     before 128+ cores), then as many frame batches as fit in ~budget_s per batch size.  `value` is the B=8 rate (the
-    batch of the headline workload); the B=1 rate sits beside it."""
-    from oracle.torch_port import TorchPort
-    t = TorchPort(synth.state_dict("sharp", "synthetic_damped"), "sharp")
+    batch of the headline workload); the B=1 rate (the batch the reference's tools run) sits beside it."""
+    t = cpu_reference_model()
+    kind = "reference" if t is not None else "port"
+    if t is None:
+        from oracle.torch_port import TorchPort
+        t = TorchPort(synth.state_dict("sharp", "synthetic_damped"), "sharp")
     ncpu = os.cpu_count() or 1
 
     def frames_per_s(B, thr, budget, max_iter):
@@ -338,13 +360,15 @@ def cpu_baseline(budget_s=10.0):
         best_thr = scan(1, cands, 0.7)
         f1, n1, e1 = frames_per_s(1, best_thr, budget_s * 0.6, 400)
         f8, n8, e8 = frames_per_s(8, thr8, budget_s, 100)
-    return {"value": round(f8, 2), "unit": "frames/sec", "cores": thr8, "kind": "port",
+    what = ("the reference's own Custom (oracle/_ref: experiments/siammask_sharp/custom.py compiled unchanged)" if kind == "reference"
+            else "torch CPU ops (oracle/torch_port.py)")
+    return {"value": round(f8, 2), "unit": "frames/sec", "cores": thr8, "kind": kind,
             "cpu_model": cpu_model_string(), "logical_cpus": ncpu,
             "b1": {"value": round(f1, 2), "cores": best_thr, "frames": n1, "seconds": round(e1, 1)},
             "b8": {"value": round(f8, 2), "cores": thr8, "frames": 8 * n8, "seconds": round(e8, 1)},
-            "sample": "sharp track_mask+track_refine, fp32, torch CPU ops (oracle/torch_port.py): %d batches of B=8 in "
+            "sample": "sharp track_mask+track_refine, fp32, %s: %d batches of B=8 in "
                       "%.1f s with %d threads and %d frames of B=1 in %.1f s with %d threads (thread counts = best of "
-                      "a short scan) on %d logical CPUs, %s" % (n8, e8, thr8, n1, e1, best_thr, ncpu, cpu_model_string())}
+                      "a short scan) on %d logical CPUs, %s" % (what, n8, e8, thr8, n1, e1, best_thr, ncpu, cpu_model_string())}
 
 
 def free_port():

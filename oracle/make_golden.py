@@ -23,8 +23,8 @@ import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.environ.get("SIAMMASK_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
+from tests.compat.shim import REF  # noqa: E402  ($SIAMMASK_REFERENCE, /root/reference, or the compiled oracle/_ref)
 sys.dont_write_bytecode = True
 warnings.filterwarnings("ignore")
 

@@ -3,6 +3,8 @@
 one JSON line on stdout (used by tests/test_dropin_tools.py).
 
     run_tool.py demo  <custom_dir> <n_frames>     # tools/demo.py, whole file, as __main__ (runpy)
+    run_tool.py trace <custom_dir> <n_frames> <out.npz>   # the same, with tools.test.siamese_track observed: per-frame
+                                                  # target_pos / target_sz / score / thresholded mask -> out.npz, wall time per frame
     run_tool.py main  <custom_dir>                # the model set-up statements of tools/test.py main() (:556-569)
                                                   # followed by siamese_init / siamese_track on two tennis frames
 
@@ -52,20 +54,42 @@ def main():
     ckpt = write_checkpoint(variant)
     out = {"mode": mode, "variant": variant, "region_ext": info["region"], "error": None}
     try:
-        if mode == "demo":
+        if mode in ("demo", "trace"):
             n = int(sys.argv[3])
+            rec = []
+            if mode == "trace":
+                # observe the unchanged tool: demo.py binds `from tools.test import *` to what the module holds at that moment
+                import time as _time
+                t = shim.load_tools_test()
+                orig_track = t.siamese_track
+
+                def observed(state, im, *a, **k):
+                    t0 = _time.perf_counter()
+                    st = orig_track(state, im, *a, **k)
+                    if torch.cuda.is_available():
+                        torch.cuda.synchronize()
+                    rec.append(dict(pos=np.array(st["target_pos"], dtype=np.float64), sz=np.array(st["target_sz"], dtype=np.float64),
+                                    score=float(st["score"]), mask=np.packbits(np.asarray(st["mask"]) > st["p"].seg_thr),
+                                    mask_shape=np.asarray(st["mask"]).shape, sec=_time.perf_counter() - t0))
+                    return st
+                t.siamese_track = observed
             frames = tempfile.mkdtemp(prefix="smk_demo_frames_")
             for i in range(n):
                 os.symlink(os.path.join(shim.REF, "data", "tennis", "%05d.jpg" % i), os.path.join(frames, "%05d.jpg" % i))
             sys.argv = ["demo.py", "--resume", ckpt, "--config", cfg_path, "--base_path", frames] + (
                 [] if torch.cuda.is_available() else ["--cpu"])
             try:
-                g = runpy.run_path(os.path.join(shim.REF, "tools", "demo.py"), run_name="__main__")
+                g = runpy.run_path(shim.ref_file("tools", "demo.py"), run_name="__main__")
             finally:
                 mod = sys.modules.get("custom")
                 out["custom_file"] = getattr(mod, "__file__", None)
                 out["custom_class_module"] = getattr(getattr(mod, "Custom", None), "__module__", None)
             st = g["state"]
+            if mode == "trace":
+                np.savez_compressed(sys.argv[4], pos=np.stack([r["pos"] for r in rec]), sz=np.stack([r["sz"] for r in rec]),
+                                    score=np.array([r["score"] for r in rec]), mask=np.stack([r["mask"] for r in rec]),
+                                    mask_shape=np.array(rec[0]["mask_shape"]), sec=np.array([r["sec"] for r in rec]))
+                out["sec_per_frame_median"] = float(np.median([r["sec"] for r in rec]))
             out.update(frames=int(g["f"]) + 1, target_pos=[float(v) for v in st["target_pos"]],
                        target_sz=[float(v) for v in st["target_sz"]], score=float(st["score"]),
                        mask_shape=list(np.asarray(st["mask"]).shape), cv2_calls=dict(cv2_stub.CALLS))
