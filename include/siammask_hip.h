@@ -230,7 +230,8 @@ int smk_op_conv2d(int dtype, int algo, const float *x_dev, int B, int Cin, int H
  *   for all layers; no windows / upsampling); g.res_mode != 0 adds the tensor res_src (-1 = x, j < i = output of layer j,
  *   same shape as the output) before / after the ReLU; sync != 0 puts a team barrier behind the layer (needed whenever a later
  *   layer reads what this one or an earlier unsynchronised one wrote); cfg = tile code 0 64x256, 1 64x128, 2 64x64,
- *   3 128x256, 4 128x128, 5 = measurement variant (64x128, deeper rings), -1 = the engine's choice; kstag = K-loop stagger
+ *   3 128x256, 4 128x128, 5..8 = measurement variants of 64x128 (5 deeper rings; 6 / 7 / 8 without activation refills /
+ *   weight refills / MFMA: wrong results by construction), -1 = the engine's choice; kstag = K-loop stagger
  *   1 / 0, -1 = the engine's choice.  w_host [Cout,Cin,k,k], b_host [Cout] or NULL; y_dev: device f32 NCHW output or NULL.
  * The launch is repeated `iters` times; *usec_out (optional) = average microseconds of launches 2..iters; clk_us_out
  * (optional, [2*n]) = per layer, the time (team 0, slot 0) spent in its tiles and in the barrier arrival, of the last launch.

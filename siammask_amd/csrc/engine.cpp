@@ -2099,7 +2099,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         SeqLayer L;
         if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
         if (op.cfg >= 0) {
-            if (op.cfg > 5) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..5");
+            if (op.cfg > 8) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..8");
             L.cfg = (signed char)op.cfg;
         }
         if (op.kstag >= 0) L.kstag = (signed char)(op.kstag != 0);

@@ -147,7 +147,7 @@ struct Tuning {
     int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
     int seq_tall = 2;          // sequences: 128-row tiles for layers that would otherwise need several 64-row rounds per image
                                // (1: short-K layers only -- the rule with two producer waves; 2: all, measured -1.7 % with four)
-    int seq_kstag = 0;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
+    int seq_kstag = 1;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
                                // weights fit the L2, 2 all)
     int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only

@@ -56,6 +56,7 @@ def main():
     try:
         if mode in ("demo", "trace"):
             n = int(sys.argv[3])
+            trace_out = sys.argv[4] if mode == "trace" else None      # (sys.argv is replaced by demo.py's own below)
             rec = []
             if mode == "trace":
                 # observe the unchanged tool: demo.py binds `from tools.test import *` to what the module holds at that moment
@@ -86,7 +87,7 @@ def main():
                 out["custom_class_module"] = getattr(getattr(mod, "Custom", None), "__module__", None)
             st = g["state"]
             if mode == "trace":
-                np.savez_compressed(sys.argv[4], pos=np.stack([r["pos"] for r in rec]), sz=np.stack([r["sz"] for r in rec]),
+                np.savez_compressed(trace_out, pos=np.stack([r["pos"] for r in rec]), sz=np.stack([r["sz"] for r in rec]),
                                     score=np.array([r["score"] for r in rec]), mask=np.stack([r["mask"] for r in rec]),
                                     mask_shape=np.array(rec[0]["mask_shape"]), sec=np.array([r["sec"] for r in rec]))
                 out["sec_per_frame_median"] = float(np.median([r["sec"] for r in rec]))
