@@ -108,8 +108,8 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
     for (int li = 0; li < a.n && alive; ++li) {
         const SeqLayer &L = a.L[li];
         const int cfg = L.cfg;
-        const int bn = (cfg == 0 || cfg == 3) ? 256 : ((cfg == 2) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
-        const int bm = (cfg == 3 || cfg == 4) ? 128 : 64;
+        const int bn = (cfg == 0 || cfg == 3) ? 256 : ((cfg == 2 || cfg == 9) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
+        const int bm = (cfg == 3 || cfg == 4 || cfg == 9) ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
         const int hw = L.Ho * L.Wo;
         const int tiles = ((hw + bm - 1) / bm) * tilesN;
@@ -132,6 +132,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
                 else if (cfg == 3) alive = wreg_tile<4, 4, 1, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 4) alive = wreg_tile<4, 2, 2, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 9) alive = wreg_tile<4, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
                 // (measurement variant: 64x128 with a 5-deep activation ring and the weight fragments FOUR K tiles ahead)
                 else if (cfg == 5) alive = wreg_tile<2, 2, 2, 5, 16, 4, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 // (measurement variants of the 64x128 tile, results wrong by construction: 6 = activation tiles never refilled,

@@ -723,7 +723,9 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
         if (tiles64 > 32) {
             if (p.Nst >= 512) L.cfg = 3;
             else if (p.Nst >= 96) L.cfg = 4;
+            else L.cfg = 9;                              // 128x64 (layer1's 64-channel convolutions on 63x63 images)
         }
+        if (tiles64 > 64 && p.Nst >= 192 && p.Nst < 512) L.cfg = 3;      // N = 256 on 63x63 images: 128x256, one round (layer1 conv3)
     }
     L.sync = 1;
     // K-loop stagger (smk_tune "seq_kstag": 0 off, 1 = layers whose weights fit the XCD's L2 beside the activations, 2 = all)
@@ -2099,7 +2101,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         SeqLayer L;
         if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
         if (op.cfg >= 0) {
-            if (op.cfg > 8) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..8");
+            if (op.cfg > 9) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..9");
             L.cfg = (signed char)op.cfg;
         }
         if (op.kstag >= 0) L.kstag = (signed char)(op.kstag != 0);

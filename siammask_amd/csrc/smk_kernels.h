@@ -89,11 +89,13 @@ struct SeqLayer {
     void *out;             // NHWC f16
     unsigned in_bytes, w_bytes;
     int kw_magic;
-    unsigned short Hs, Ws, Cs, cin_off, Ci, Hl, Wl, Ho, Wo, Kpad, Nst, Cos, cout_off, res_Cs, res_coff;
+    // 16-bit fields in 4-byte aligned PAIRS that are read together: the compiler fetches a pair with one scalar load (a pair that
+    // straddles a dword boundary becomes a VECTOR load from the kernel-argument segment -- and a vmcnt wait in the producers)
+    unsigned short Hs, Ws, Hl, Wl, Ho, Wo, Cs, cin_off, Ci, Kpad, Nst, Cos, res_Cs, res_coff, cout_off, pad16_;
     short org_y, org_x;
     signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
-    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128;
-                           //   measurement variants: 5 = 64x128 with a 5-deep ring and weights 4 K tiles ahead
+    signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128, 9 = 128x64;
+                           //   measurement variants: 5 = 64x128 with a 5-deep ring and weights 4 K tiles ahead, 6..8 ablations
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
     signed char a_stage;   // see ConvParams::a_stage
     signed char kstag;     // 1: every workgroup starts its K loop at another K tile (see wreg_tile kt0)

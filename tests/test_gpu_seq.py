@@ -16,7 +16,7 @@ from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-3
-TILES = [(64, 256), (64, 128), (64, 64), (128, 256), (128, 128), "deep"]
+TILES = [(64, 256), (64, 128), (64, 64), (128, 256), (128, 128), (128, 64), "deep"]
 
 
 def _ops():
