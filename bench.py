@@ -237,8 +237,8 @@ def roofline(w, steps=3):
     for r in recs:
         k = r["kernel"].split("<")[0]
         k = CONV_FAMILY if k in CONV_KERNELS else k     # the per-launch MFMA implicit-GEMM conv kernels as one family
-        f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0})
-        f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["bytes"] += r["bytes"]; f["calls"] += r["calls"]
+        f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0, "ext": 0.0})
+        f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["bytes"] += r["bytes"]; f["calls"] += r["calls"]; f["ext"] += r.get("ext_bytes", 0.0)
     total_ms = sum(f["ms"] for f in fam.values())
     dom = max(fam, key=lambda k: fam[k]["ms"])
     d = fam[dom]
@@ -268,22 +268,45 @@ def roofline(w, steps=3):
     # HBM bytes per launch from the PMC counters (collected offline by tools/measure/gpu_pmc.sh with rocprofv3
     # --pmc in separate passes and committed under profiles/; cannot be sampled from inside this process)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % w.name)
+    out["traffic"] = None
     if os.path.exists(pmc):
         try:
+            sys.path.insert(0, os.path.join(REPO, "tools", "measure"))
+            from src_hash import kernel_sources_sha256
             t = json.load(open(pmc))
-            bk = t.get("by_kernel", {}).get(dom + "_kernel")
-            if bk:
-                out["traffic"] = bk["hbm_bytes_per_launch_corrected"]
-                out["traffic_note"] = "fabric-side bytes per launch of %s (Infinity-Cache hits included); %s; %s" % (dom, t["source"], t["correction"])
+            if t.get("kernel_sources_sha256") != kernel_sources_sha256():
+                # a PMC summary of other kernel sources says nothing about this binary: report no traffic rather than a stale one
+                out["traffic_note"] = ("profiles/%s was measured on other kernel sources (sha256 %s...); re-run tools/measure/gpu_pmc.sh"
+                                       % (os.path.basename(pmc), str(t.get("kernel_sources_sha256"))[:12]))
             else:
-                out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
-                out["traffic_note"] = "bytes per launch of the per-launch conv kernels; %s; %s" % (t["source"], t["correction"])
+                bk = t.get("by_kernel", {}).get(dom + "_kernel")
+                if bk:
+                    out["traffic"] = bk["hbm_bytes_per_launch_corrected"]
+                    out["traffic_note"] = "fabric-side bytes per launch of %s (Infinity-Cache hits included), measured on exactly these kernel sources (sha256 %s...); %s; %s" % (
+                        dom, t["kernel_sources_sha256"][:12], t["source"], t["correction"])
+                else:
+                    out["traffic"] = t["conv_igemm_family"]["hbm_bytes_per_launch_corrected"]
+                    out["traffic_note"] = "bytes per launch of the per-launch conv kernels; %s; %s" % (t["source"], t["correction"])
         except Exception:  # noqa: BLE001
             pass
     out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))
+    if d.get("ext", 0.0) > 0:
+        # conv_seq: the bytes that must cross the fabric when every tensor produced and consumed inside the launch stays in
+        # the XCD's L2 (inputs of the sequence, every weight pack once, p2 and the sequence's final output)
+        out["external_bytes_per_launch"] = int(d["ext"] / max(1, d["calls"]))
     if xc and xc["ms"] > 0:
         out["dw_xcorr"] = {"bound": "hbm", "achieved_GBps": round(xc["bytes"] / (xc["ms"] * 1e-3) / 1e9, 1),
-                           "peak_GBps": 8000.0, "us": round(xc["ms"] * 1e3 / xc["calls"], 2)}
+                           "peak_GBps": 8000.0, "frac": round(xc["bytes"] / (xc["ms"] * 1e-3) / 1e9 / 8000.0, 4),
+                           "us": round(xc["ms"] * 1e3 / xc["calls"], 2),
+                           "algorithmic_bytes_per_launch": int(xc["bytes"] / max(1, xc["calls"])), "traffic": None}
+        try:                                              # fabric-side bytes of the same kernel sources, if measured
+            t = json.load(open(pmc))
+            if t.get("kernel_sources_sha256") == kernel_sources_sha256():
+                bk = t.get("by_kernel", {}).get("dw_xcorr_full_kernel") or t.get("by_kernel", {}).get("dw_xcorr_kernel")
+                if bk:
+                    out["dw_xcorr"]["traffic"] = bk["hbm_bytes_per_launch_corrected"]
+        except Exception:  # noqa: BLE001
+            pass
     return out, recs
 
 

@@ -156,7 +156,8 @@ int smk_set_graph_mode(smk_ctx *ctx, int enable);
  *   "force_tile" 0 auto | 1 128x128 | 2 128x64 | 3 64x128 | 4 64x64 | 5 256x128   "kt" 0|128|256 (K-tile bytes)
  *   "stages" 0|2|3|4 (LDS ring depth)     "xcd_mode" 0|1|2 (tile -> XCD order)   "min_blocks_x16" (tile thresholds)
  *   "merge" 0|1 (independent convolutions share a launch)   "nt_store" 0|1 (streaming stores of the mask logits)
- *   "buf_lds" 0|1 (LDS-DMA through buffer resources; default 1)   "xc_ch" 64|32 (dw-xcorr channels per workgroup; null)
+ *   "buf_lds" 0|1 (LDS-DMA through buffer resources; default 1)   "xc_ch" 64|32 (banded dw-xcorr: channels per workgroup; null)
+ *   "xc_full" 0|1 (dw-xcorr: one workgroup = 32 channels x the whole image, every input byte read once; default 1)
  *   "prio" -1..3 (s_setprio of the consumer waves; measured null)   "mask_overlap" 0|1 (mask head on a graph side
  *   branch; measured slower)   "concurrency" 0|1 (fork/join between independent launches; measured slower; applies to
  *   contexts created afterwards)

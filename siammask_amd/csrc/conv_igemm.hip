@@ -260,36 +260,43 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
         // are recomputed only when it changes (scalar branch); otherwise they are recomputed per
         // tile.  Padding (conv zero padding, rows >= M, K tail) reads the zero page, so the loads
         // are branch-free.
-        const bool tap_uniform = p.ci_shift >= 0 && p.Ci >= BK;
+        // The geometry the K loop needs, as OPAQUE scalar copies (see wreg_tile.inc: without this the compiler re-loads the
+        // fields from the kernel-argument segment wherever the tap changes inside the loop, and waits for them)
+        auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        int g_kwm = sgpr(p.kw_magic), g_kw = sgpr(p.kw), g_kh = sgpr(p.kh), g_dil = sgpr(p.dil), g_Hl = sgpr(p.Hl), g_Wl = sgpr(p.Wl),
+            g_Hs = sgpr(p.Hs), g_Ws = sgpr(p.Ws), g_Cs = sgpr(p.Cs), g_cish = sgpr(p.ci_shift), g_Ci = sgpr(p.Ci), g_ups = sgpr(p.ups);
+        asm volatile("" : "+s"(g_kwm), "+s"(g_kw), "+s"(g_kh), "+s"(g_dil), "+s"(g_Hl), "+s"(g_Wl));
+        asm volatile("" : "+s"(g_Hs), "+s"(g_Ws), "+s"(g_Cs), "+s"(g_cish), "+s"(g_Ci), "+s"(g_ups));
+        const bool tap_uniform = g_cish >= 0 && g_Ci >= BK;
         int cur_tap_s = -1;                                // wave-uniform tap of the last decode
         int cur_c = 0;
         long a_off[RA];                                    // byte offsets relative to `in`
         auto tap_offsets = [&](int tap) {
-            const int kh_i = (tap * p.kw_magic) >> 16;
-            const int kw_i = tap - kh_i * p.kw;
-            const bool tap_ok = kh_i < p.kh;
+            const int kh_i = (tap * g_kwm) >> 16;
+            const int kw_i = tap - kh_i * g_kw;
+            const bool tap_ok = kh_i < g_kh;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                const int ly = ri[i].ly0 + kh_i * p.dil, lx = ri[i].lx0 + kw_i * p.dil;
-                bool ok = rvalid[i] & tap_ok & ((unsigned)ly < (unsigned)p.Hl) & ((unsigned)lx < (unsigned)p.Wl);
+                const int ly = ri[i].ly0 + kh_i * g_dil, lx = ri[i].lx0 + kw_i * g_dil;
+                bool ok = rvalid[i] & tap_ok & ((unsigned)ly < (unsigned)g_Hl) & ((unsigned)lx < (unsigned)g_Wl);
                 int sy, sx;
-                if (p.ups) {                               // nearest upsampling (uniform branch)
-                    sy = (ly * p.Hs) / p.Hl;
-                    sx = (lx * p.Ws) / p.Wl;
+                if (g_ups) {                               // nearest upsampling (uniform branch)
+                    sy = (ly * g_Hs) / g_Hl;
+                    sx = (lx * g_Ws) / g_Wl;
                 } else {
                     sy = ly + ri[i].oy_org;
                     sx = lx + ri[i].ox_org;
                 }
-                ok = ok & ((unsigned)sy < (unsigned)p.Hs) & ((unsigned)sx < (unsigned)p.Ws);
-                const long off = (((long)(ri[i].b * p.Hs + sy) * p.Ws + sx) * p.Cs + cin_off) * (long)sizeof(T);
+                ok = ok & ((unsigned)sy < (unsigned)g_Hs) & ((unsigned)sx < (unsigned)g_Ws);
+                const long off = (((long)(ri[i].b * g_Hs + sy) * g_Ws + sx) * g_Cs + cin_off) * (long)sizeof(T);
                 a_off[i] = ok ? off : (use_buf ? OOB : zero_off);
             }
         };
         auto set_tile = [&](int kt) {
             if (tap_uniform) {
                 const int k0 = kt * BK;
-                const int tap = k0 >> p.ci_shift;
-                cur_c = (k0 & (p.Ci - 1)) + slot * VE;
+                const int tap = k0 >> g_cish;
+                cur_c = (k0 & (g_Ci - 1)) + slot * VE;
                 if (tap != cur_tap_s) {
                     cur_tap_s = tap;
                     tap_offsets(tap);
@@ -297,8 +304,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
             } else {
                 const int k = kt * BK + slot * VE;
                 int tap;
-                if (p.ci_shift >= 0) { tap = k >> p.ci_shift; cur_c = k & (p.Ci - 1); }
-                else { tap = k / p.Ci; cur_c = k - tap * p.Ci; }
+                if (g_cish >= 0) { tap = k >> g_cish; cur_c = k & (g_Ci - 1); }
+                else { tap = k / g_Ci; cur_c = k - tap * g_Ci; }
                 tap_offsets(tap);
             }
         };

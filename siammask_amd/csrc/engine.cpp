@@ -244,7 +244,7 @@ struct smk_ctx {
 
     // per-launch profiling (smk_profile): HIP events around every kernel, eager mode only
     bool prof = false;
-    struct ProfRec { std::string id, kernel; double flop, bytes; hipEvent_t e0, e1; };
+    struct ProfRec { std::string id, kernel; double flop, bytes; hipEvent_t e0, e1; double ext_bytes = 0.0; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     size_t prof_pool_next = 0;
@@ -258,7 +258,7 @@ struct ProfScope {
     ProfScope(smk_ctx *c_, hipStream_t s_, const std::string &id, const std::string &kernel, double flop,
               double bytes) : c(c_), s(s_) {
         if (!c->prof) return;
-        smk_ctx::ProfRec r{id, kernel, flop, bytes, nullptr, nullptr};
+        smk_ctx::ProfRec r{id, kernel, flop, bytes, nullptr, nullptr, 0.0};
         // events come from a pool created by smk_profile(1): creating them between launches
         // stalled the stream at a fixed position (one layer read 10x too long)
         if (c->prof_pool_next + 2 > c->prof_pool.size()) return;
@@ -269,6 +269,8 @@ struct ProfScope {
         idx = (int)c->prof_recs.size() - 1;
     }
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].e1, s); }
+    // bytes that have to cross the XCD's fabric port even when every inter-layer tensor of the launch stays in its L2
+    void ext_bytes(double b) { if (idx >= 0) c->prof_recs[idx].ext_bytes = b; }
     void cancel() { if (idx >= 0 && idx == (int)c->prof_recs.size() - 1) { c->prof_recs.pop_back(); c->prof_pool_next -= 2; } idx = -1; }
 };
 
@@ -778,6 +780,31 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         snprintf(idn, sizeof(idn), "seq[%s..%s]", c->seq_ids[i0].c_str(), c->seq_ids[i0 + a.n - 1].c_str());
         const double fr = (double)a.n / (double)n;
         ProfScope ps(c, s, idn, "conv_seq", c->seq_flop * fr, c->seq_bytes * fr);
+        {   // what must cross the fabric if every tensor produced AND consumed inside the launch stays in the XCD's L2:
+            // tensors read but not produced here, every weight pack once, tensors produced here and not read here (+ p2,
+            // which Refine reads later)
+            double ext = 0.0;
+            for (int i = 0; i < a.n; ++i) {
+                const SeqLayer &L = a.L[i];
+                bool in_inside = false, res_inside = L.res == nullptr, out_read = false;
+                for (int j = 0; j < a.n; ++j) {
+                    if (j < i && a.L[j].out == L.in) in_inside = true;
+                    if (j < i && L.res && a.L[j].out == L.res) res_inside = true;
+                    if (j > i && (a.L[j].in == L.out || a.L[j].res == L.out)) out_read = true;
+                }
+                bool in_counted = false, res_counted = false;          // a tensor several layers read is fetched once
+                for (int j = 0; j < i; ++j) {
+                    if (a.L[j].in == L.in || a.L[j].res == L.in) in_counted = true;
+                    if (L.res && (a.L[j].in == L.res || a.L[j].res == L.res)) res_counted = true;
+                }
+                const double px_in = (double)B * L.Hs * L.Ws, px_out = (double)B * L.Ho * L.Wo;
+                ext += (double)L.Nst * L.Kpad * 2.0;
+                if (!in_inside && !in_counted) ext += px_in * L.Cs * 2.0;
+                if (!res_inside && !res_counted) ext += px_out * L.res_Cs * 2.0;
+                if (!out_read || L.out == c->buf.at("p2")) ext += px_out * L.Nst * 2.0;
+            }
+            ps.ext_bytes(ext);
+        }
         if (launch_conv_seq(a, c->seq_grid, s))
             return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
         if (want_clk) {                                  // per-layer spans of (team 0, slot 0), eager mode only
@@ -1394,6 +1421,7 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
     if (rc) return rc;
     if (!zero_page()) return fail(SMK_E_HIP, "could not allocate the zero page");   // before any capture
     c->seq_grid = seq_grid_for(prop.multiProcessorCount);
+    xcorr_prepare();
     for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
     c->ev_pool.resize(64);
     for (auto &e : c->ev_pool) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1685,6 +1713,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;
     else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
+    else if (!strcmp(key, "xc_full")) g_tune.xc_full = value != 0;
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
@@ -1708,7 +1737,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_deep", &g_tune.seq_deep},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
-        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch},
+        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full},
         {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
@@ -1733,7 +1762,7 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
     if (!c || !buf || cap < 64) return fail(SMK_E_ARG, "smk_profile_dump: bad argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    struct Agg { std::string kernel; double ms = 0, flop = 0, bytes = 0; int calls = 0; };
+    struct Agg { std::string kernel; double ms = 0, flop = 0, bytes = 0, ext = 0; int calls = 0; };
     std::vector<std::pair<std::string, Agg>> order;
     std::map<std::string, size_t> idx;
     for (auto &r : c->prof_recs) {
@@ -1742,7 +1771,7 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
         auto it = idx.find(r.id);
         if (it == idx.end()) { idx[r.id] = order.size(); order.push_back({r.id, Agg()}); it = idx.find(r.id); }
         Agg &a = order[it->second].second;
-        a.kernel = r.kernel; a.ms += ms; a.flop += r.flop; a.bytes += r.bytes; a.calls++;
+        a.kernel = r.kernel; a.ms += ms; a.flop += r.flop; a.bytes += r.bytes; a.ext += r.ext_bytes; a.calls++;
     }
     c->prof_recs.clear();
     c->prof_pool_next = 0;
@@ -1750,8 +1779,8 @@ int smk_profile_dump(smk_ctx *c, char *buf, int cap) {
     for (size_t i = 0; i < order.size(); ++i) {
         char line[512];
         const Agg &a = order[i].second;
-        snprintf(line, sizeof(line), "%s{\"id\":\"%s\",\"kernel\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flop\":%.6e,\"bytes\":%.6e}",
-                 i ? "," : "", order[i].first.c_str(), a.kernel.c_str(), a.calls, a.ms, a.flop, a.bytes);
+        snprintf(line, sizeof(line), "%s{\"id\":\"%s\",\"kernel\":\"%s\",\"calls\":%d,\"ms\":%.6f,\"flop\":%.6e,\"bytes\":%.6e,\"ext_bytes\":%.6e}",
+                 i ? "," : "", order[i].first.c_str(), a.kernel.c_str(), a.calls, a.ms, a.flop, a.bytes, a.ext);
         js += line;
     }
     js += "]";

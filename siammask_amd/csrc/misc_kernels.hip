@@ -119,6 +119,98 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
         }
 }
 
+// Full-height variant (round 3): workgroup = (32 channels) x (the WHOLE image of one batch item).  The banded kernel above
+// re-reads kh - 1 of every XC_BR + kh - 1 input rows (1.8x the input at 5-row bands: 25.3 MB fabric-side for 18.3 MB
+// algorithmic at B = 8) and its 480 small workgroups each pay a full load -> compute -> store latency chain.  Here every input
+// byte is read exactly once (29 x 29 x 32 channels = 54 KB of fp16 in LDS), 24 x B workgroups of 13 waves; a thread owns a
+// channel pair and a half-row strip as before and walks the output rows strip by strip.
+template <typename T, int XC_CH>
+__global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    constexpr int VE = 16 / (int)sizeof(T);
+    constexpr int VPP = XC_CH / VE;
+    const int c0 = blockIdx.x * XC_CH, b = blockIdx.y;
+    T *sx = (T *)xsm;                                // [H][W][XC_CH]
+    T *sk = sx + (size_t)p.H * p.W * XC_CH;          // [kh*kw][XC_CH]
+    const T *x = (const T *)p.x;
+    const T *k = (const T *)p.k;
+    const int nthr = blockDim.x;
+    const int nvk = p.kh * p.kw * VPP;
+    for (int v = threadIdx.x; v < nvk; v += nthr) {
+        const int tap = v / VPP, q = v - tap * VPP;
+        const size_t g = ((size_t)b * p.kh * p.kw + tap) * p.Cs + c0 + q * VE;
+        *(uint4 *)(sk + (size_t)tap * XC_CH + q * VE) = *(const uint4 *)(k + g);
+    }
+    const int nvx = p.H * p.W * VPP;
+    const size_t xb = (size_t)b * p.H * p.W * p.Cs + c0;
+    for (int v = threadIdx.x; v < nvx; v += nthr) {
+        const int pix = v / VPP, q = v - pix * VPP;
+        *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = *(const uint4 *)(x + xb + (size_t)pix * p.Cs + q * VE);
+    }
+    __syncthreads();
+
+    constexpr int NCP = XC_CH / 2;
+    const int cp = threadIdx.x % NCP;
+    const int strip = threadIdx.x / NCP, nstrip = nthr / NCP;
+    const int wfirst = (p.Wo + 1) / 2;
+    T *out = (T *)p.out;
+    for (int sidx = strip; sidx < 2 * p.Ho; sidx += nstrip) {
+        const int ri = sidx >> 1, half = sidx & 1;
+        const int j0 = half ? wfirst : 0;
+        const int jn = half ? p.Wo - wfirst : wfirst;
+        floatx2 acc[XC_SW];
+#pragma unroll
+        for (int j = 0; j < XC_SW; ++j) acc[j] = floatx2{0.f, 0.f};
+        for (int u = 0; u < p.kh; ++u) {
+            floatx2 tap[XC_KMAX];
+#pragma unroll
+            for (int v = 0; v < XC_KMAX; ++v)
+                tap[v] = v < p.kw ? P2<T>::ld(sk + (size_t)(u * p.kw + v) * XC_CH + cp * 2) : floatx2{0.f, 0.f};
+            const T *srow = sx + (size_t)((ri + u) * p.W + j0) * XC_CH + cp * 2;
+#pragma unroll
+            for (int t = 0; t < XC_SW + XC_KMAX - 1; ++t) {
+                floatx2 xv = floatx2{0.f, 0.f};
+                if (t < jn + p.kw - 1) xv = P2<T>::ld(srow + (size_t)t * XC_CH);
+#pragma unroll
+                for (int v = 0; v < XC_KMAX; ++v) {
+                    const int jj = t - v;
+                    if (jj >= 0 && jj < XC_SW) {
+                        acc[jj][0] = fmaf(xv[0], tap[v][0], acc[jj][0]);
+                        acc[jj][1] = fmaf(xv[1], tap[v][1], acc[jj][1]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XC_SW; ++j)
+            if (j < jn) {
+                const size_t g = ((size_t)(b * p.Ho + ri) * p.Wo + j0 + j) * p.Cs + c0 + cp * 2;
+                P2<T>::st(out + g, acc[j]);
+            }
+    }
+}
+
+// more than 64 KB of dynamic LDS needs an opt-in per kernel; done once per process, outside any stream capture
+void xcorr_prepare() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void *)dw_xcorr_full_kernel<_Float16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_xcorr_full_kernel<float, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    done = true;
+}
+
+template <typename T>
+static bool launch_xcorr_full(const XcorrParams &p, hipStream_t s) {
+    constexpr int CH = 32;
+    const size_t lds = ((size_t)p.H * p.W + (size_t)p.kh * p.kw) * CH * sizeof(T);
+    if (lds > 150 * 1024 || p.C % CH != 0) return false;
+    xcorr_prepare();                                 // (no-op after the first call; smk_create calls it before any capture)
+    int strips = 2 * p.Ho;                           // one (row, half) strip per thread group of CH / 2 threads, <= 1024 threads
+    if (strips * (CH / 2) > 1024) strips = 1024 / (CH / 2);
+    hipLaunchKernelGGL((dw_xcorr_full_kernel<T, CH>), dim3(p.C / CH, p.B), dim3(strips * (CH / 2)), lds, s, p);
+    return true;
+}
+
 template <typename T, int CH>
 static void launch_xcorr_t(const XcorrParams &p, hipStream_t s) {
     const int bands = (p.Ho + XC_BR - 1) / XC_BR;
@@ -131,6 +223,10 @@ static void launch_xcorr_t(const XcorrParams &p, hipStream_t s) {
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
     if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % 64 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
+    if (g_tune.xc_full) {                                // the whole image of a 32-channel chunk per workgroup (default)
+        const bool ok = dtype == DT_F16 ? launch_xcorr_full<_Float16>(p, s) : launch_xcorr_full<float>(p, s);
+        if (ok) return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     const bool c32 = g_tune.xc_ch == 32;
     if (dtype == DT_F16) { if (c32) launch_xcorr_t<_Float16, 32>(p, s); else launch_xcorr_t<_Float16, 64>(p, s); }
     else { if (c32) launch_xcorr_t<float, 32>(p, s); else launch_xcorr_t<float, 64>(p, s); }

@@ -133,7 +133,8 @@ struct Tuning {
     int chain = 1;             // fp16: Refine's sequential tail as one launch (refine_chain_kernel)
     int ksplit = 0;            // split-K across workgroups: 0 off (default: measured a net loss at B=8, +1 % at B=1,
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
-    int xc_ch = 64;            // dw_xcorr: channels per workgroup (64 or 32)
+    int xc_ch = 64;            // dw_xcorr, banded kernel: channels per workgroup (64 or 32)
+    int xc_full = 1;           // dw_xcorr: one workgroup = 32 channels x the whole image (every input byte read once); 0 = 5-row bands
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
@@ -300,6 +301,7 @@ int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch
 int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
+void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);

@@ -4,7 +4,11 @@ HBM bytes per launch of the MFMA convolution kernels (conv_igemm_kernel + conv3x
 corrected as MI355X_MICROARCH.md prescribes for gfx950.
 usage: pmc_traffic.py <pmc_by_kernel.json> <workload> <source label> > profiles/pmc_traffic_<workload>.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_hash import kernel_sources_sha256
 
 src, workload, label = sys.argv[1], sys.argv[2], sys.argv[3]
 d = json.load(open(src))
@@ -39,7 +43,8 @@ def one(name):
 
 
 out = {"workload": workload,
-       "by_kernel": {n: one(n) for n in ("conv_seq_kernel", "chain_mask_kernel", "dw_xcorr_kernel") if one(n)},
+       "kernel_sources_sha256": kernel_sources_sha256(),
+       "by_kernel": {n: one(n) for n in ("conv_seq_kernel", "chain_mask_kernel", "dw_xcorr_full_kernel", "dw_xcorr_kernel") if one(n)},
        "source": "%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, tools/measure/gpu_pmc.sh)" % label,
        "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                      "WRITE_SIZE as reported (uncalibrated)",
