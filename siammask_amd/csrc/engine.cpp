@@ -1023,21 +1023,31 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
     const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
     const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
     const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
-    Act xin = act(c, "xin", S, (S + 1) / 2, 8);            // pixel-pair layout (see pack_stem)
-    CvtInParams ci{x, xin.p, B, 3, S, S, 8, 1};
-    {
-        ProfScope ps(c, s, "cvt_in", "cvt_in", 0.0, (double)B * S * S * (3 * 4 + 8 * esize(c->dtype)));
-        if (launch_cvt_in(ci, c->dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
-    }
     Act p0 = act(c, "p0", s0, s0, 64);
-    ConvOpt o;
-    o.stride = 2; o.stride_x = 1; o.relu = 1;
-    CHK(run_conv(c, "stem", xin, &p0, B, o, s));
     Act x1 = act(c, "x1", s1, s1, 64);
-    PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1};
-    {
-        ProfScope ps(c, s, "maxpool", "maxpool", 0.0, (double)B * 64 * esize(c->dtype) * (s0 * s0 + s1 * s1));
-        if (launch_maxpool(pp, c->dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");
+    auto stem_it = c->conv.find("stem");
+    if (stem_it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv stem not packed");
+    if (c->dtype == DT_F16 && g_tune.stem_fused && stem_it->second.w_frag) {
+        // one launch: frame -> p0 (kept for Refine) -> pooled x1, the p0 tile never leaves LDS in between (stem_pool.hip)
+        StemPoolParams sp_{x, stem_it->second.w_frag, stem_it->second.bias, p0.p, x1.p, B, S, s0, s1, stem_it->second.Kpad};
+        ProfScope ps(c, s, "stem_pool", "stem_pool", 2.0 * B * s0 * s0 * 64.0 * 147.0,
+                     (double)B * (3.0 * S * S * 4 + ((double)s0 * s0 + (double)s1 * s1) * 64 * 2));
+        if (launch_stem_pool(sp_, s)) return fail(SMK_E_HIP, "stem_pool launch failed: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+        Act xin = act(c, "xin", S, (S + 1) / 2, 8);            // pixel-pair layout (see pack_stem)
+        CvtInParams ci{x, xin.p, B, 3, S, S, 8, 1};
+        {
+            ProfScope ps(c, s, "cvt_in", "cvt_in", 0.0, (double)B * S * S * (3 * 4 + 8 * esize(c->dtype)));
+            if (launch_cvt_in(ci, c->dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+        }
+        ConvOpt o;
+        o.stride = 2; o.stride_x = 1; o.relu = 1;
+        CHK(run_conv(c, "stem", xin, &p0, B, o, s));
+        PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1};
+        {
+            ProfScope ps(c, s, "maxpool", "maxpool", 0.0, (double)B * 64 * esize(c->dtype) * (s0 * s0 + s1 * s1));
+            if (launch_maxpool(pp, c->dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");
+        }
     }
 
     Act cur = x1;
@@ -1714,6 +1724,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_full")) g_tune.xc_full = value != 0;
+    else if (!strcmp(key, "stem_fused")) g_tune.stem_fused = value != 0;
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
@@ -1737,7 +1748,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_deep", &g_tune.seq_deep},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
-        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full},
+        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused},
         {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)

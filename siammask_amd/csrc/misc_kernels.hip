@@ -62,11 +62,27 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
 
     const int nvx = rows_in * p.W * VPP;
     const int nthr = blockDim.x;
-    for (int v = threadIdx.x; v < nvx; v += nthr) {
-        const int pix = v / VPP, q = v - pix * VPP;
-        const int r = pix / p.W, col = pix - r * p.W;
-        const size_t g = ((size_t)(b * p.H + i0 + r) * p.W + col) * p.Cs + c0 + q * VE;
-        *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = *(const uint4 *)(x + g);
+    // all of a thread's 16-byte loads are in flight before the first LDS write (round 3: a load -> ds_write loop, which is
+    // what the compiler makes of the obvious form, serialises one memory latency per iteration -- 7 of them here)
+    constexpr int NLD = 8;
+    const size_t xb = ((size_t)(b * p.H + i0) * p.W) * p.Cs + c0;       // the band's rows are contiguous pixels
+    for (int v0 = threadIdx.x; v0 < nvx; v0 += NLD * nthr) {
+        uint4 r[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int v = min(v0 + i * nthr, nvx - 1);
+            const int pix = v / VPP, q = v - pix * VPP;
+            r[i] = *(const uint4 *)(x + xb + (size_t)pix * p.Cs + q * VE);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int v = v0 + i * nthr;
+            if (v < nvx) {
+                const int pix = v / VPP, q = v - pix * VPP;
+                *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = r[i];
+            }
+        }
     }
     const int nvk = p.kh * p.kw * VPP;
     for (int v = threadIdx.x; v < nvk; v += nthr) {

@@ -134,6 +134,7 @@ struct Tuning {
     int ksplit = 0;            // split-K across workgroups: 0 off (default: measured a net loss at B=8, +1 % at B=1,
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
     int xc_ch = 64;            // dw_xcorr, banded kernel: channels per workgroup (64 or 32)
+    int stem_fused = 1;        // fp16: cvt_in + stem + maxpool as ONE launch (stem_pool_kernel); 0 = the three launches of rounds 1-2
     int xc_full = 1;           // dw_xcorr: one workgroup = 32 channels x the whole image (every input byte read once); 0 = 5-row bands
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
@@ -219,6 +220,8 @@ struct XcorrParams {
 };
 
 struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
+// the fused stem (stem_pool.hip): NCHW f32 frame -> conv1 7x7/2 + BN + ReLU -> p0 [B][s0][s0][64] -> maxpool 3x3/2 p1 -> x1 [B][s1][s1][64], f16
+struct StemPoolParams { const float *in; const void *wgt_frag; const float *bias; void *p0; void *x1; int B, S, s0, s1, Kpad; };
 
 struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; };  // NCHW f32 -> NHWC dtype
 // pairs = 1 (stem input, C <= 4): [B][H][ceil(W/2)][2 pixels x 4 channels], missing pixel / channel = 0
@@ -303,6 +306,7 @@ int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
+int launch_stem_pool(const StemPoolParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);

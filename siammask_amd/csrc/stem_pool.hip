@@ -1,0 +1,144 @@
+// stem_pool.hip -- the ResNet stem as ONE launch (fp16): NCHW-f32 frame -> conv1 7x7 stride 2 pad 0 + BN + ReLU -> p0 (NHWC,
+// kept for Refine) -> maxpool 3x3 stride 2 pad 1 -> x1 (NHWC).   experiments/siammask_sharp/resnet.py:154-158,217-221.
+//
+// Before (rounds 1-2): cvt_in (NCHW f32 -> pixel-pair NHWC f16, 14 MB), the stem as an implicit GEMM launch (reads those
+// 4 MB, writes the 16 MB p0), maxpool (reads the 16 MB again, writes 4 MB): three launches, 36 us of the 0.7 ms B = 8 step at
+// 1-2 TB/s.  Here a workgroup owns an 8 x 8 tile of POOLED outputs: it needs the 17 x 17 p0 pixels under them (rows
+// 2py - 1 .. 2py + 15), which need a 39 x 39 x 3 input patch.  The patch is converted on the way into LDS, p0 is computed with
+// v_mfma_f32_32x32x16_f16 against weights every wave holds in REGISTERS for the whole tile (64 x 224 fp16 = 112 VGPRs, the
+// fragment-order pack conv_wreg uses), written to LDS as fp16, and from there (a) the 16 x 16 pixels the tile owns go to
+// p0 in HBM with full 128-byte lines and (b) the 3 x 3 / 2 maxima go to x1.  The one-pixel p0 halo is recomputed by the
+// neighbouring tile (17^2 / 16^2 = +13 % MFMA work on a layer that is 1 % of the FLOPs).  K order = the pixel-pair order of
+// pack_stem: k = (ky * 4 + kx / 2) * 8 + (kx & 1) * 4 + c, K = 224 (kx = 7 and c = 3 carry zero weights), so an MFMA A
+// fragment (8 consecutive k) is 16 contiguous bytes of a [y][x][4 halves] patch at an even x -- one aligned ds_read_b128.
+#include <hip/hip_runtime.h>
+#include "smk_kernels.h"
+
+namespace smk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+constexpr int SP_TP = 8;                         // pooled outputs per tile side
+constexpr int SP_R = 2 * SP_TP + 1;              // p0 pixels per tile side (17)
+constexpr int SP_PH = 2 * SP_R + 5;              // input patch rows (39)
+constexpr int SP_PW = 2 * SP_R + 6;              // input patch columns incl. the zero-weight 8th tap (40)
+constexpr int SP_NPIX = SP_R * SP_R;             // 289
+constexpr int SP_MB = (SP_NPIX + 31) / 32;       // MFMA row blocks (10)
+constexpr int SP_KS = 14;                        // k-steps of 16: 7 rows x 2 (four taps each)
+constexpr int SP_PATCH_BYTES = SP_PH * SP_PW * 8;            // 12480
+constexpr int SP_P0_BYTES = SP_MB * 32 * 128;                // 320 pixels x 64 channels fp16 = 40960
+constexpr int SP_LDS = SP_PATCH_BYTES + SP_P0_BYTES;
+
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SP_LDS];
+    _Float16 *patch = (_Float16 *)smem;                       // [SP_PH][SP_PW][4]
+    _Float16 *p0t = (_Float16 *)(smem + SP_PATCH_BYTES);      // [320][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tpr = (p.s1 + SP_TP - 1) / SP_TP;               // tiles per row
+    const int b = blockIdx.x / (tpr * tpr);
+    const int tt = blockIdx.x - b * (tpr * tpr);
+    const int ty0 = (tt / tpr) * SP_TP, tx0 = (tt - (tt / tpr) * tpr) * SP_TP;      // first pooled output of the tile
+    const int r0 = 2 * ty0 - 1, c0 = 2 * tx0 - 1;             // first p0 pixel of the tile (may be -1: pool padding)
+    const int iy0 = 2 * r0, ix0 = 2 * c0;                     // first input pixel of the patch
+
+    // ---- weights: every wave keeps all 14 x 2 fragments (the two 32-channel blocks) in registers -------------------------
+    const uint4v *wf = (const uint4v *)p.wgt_frag;            // [Npad/32][Kpad/16][64 lanes] x 16 B
+    const int ks16 = p.Kpad >> 4;
+    half8 wb[SP_KS][2];
+#pragma unroll
+    for (int s = 0; s < SP_KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wb[s][j] = __builtin_bit_cast(half8, wf[((size_t)j * ks16 + s) * 64 + lane]);
+
+    // ---- input patch: NCHW f32 -> [y][x][c0 c1 c2 0] fp16 in LDS (coalesced along x; outside the frame -> 0) ------------
+    const size_t plane = (size_t)p.S * p.S;
+    const float *img = p.in + (size_t)b * 3 * plane;
+    for (int i = tid; i < SP_PH * SP_PW; i += 256) {
+        const int y = i / SP_PW, x = i - y * SP_PW;
+        const int gy = iy0 + y, gx = ix0 + x;
+        const bool ok = (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
+        const size_t o = ok ? (size_t)gy * p.S + gx : 0;
+        const float v0 = img[o], v1 = img[o + plane], v2 = img[o + 2 * plane];
+        half4 h = {(_Float16)(ok ? v0 : 0.f), (_Float16)(ok ? v1 : 0.f), (_Float16)(ok ? v2 : 0.f), (_Float16)0.f};
+        *(half4 *)(patch + (size_t)i * 4) = h;
+    }
+    __syncthreads();
+
+    // ---- p0 tile: 32-pixel row blocks, two 32-channel column blocks, 14 k-steps; bias + ReLU -> fp16 -> LDS ---------------
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int mb = wave; mb < SP_MB; mb += 4) {
+        int m = mb * 32 + frow;
+        if (m >= SP_NPIX) m = SP_NPIX - 1;                    // (the last block is ragged: its extra rows are never read)
+        const int py = m / SP_R, px = m - py * SP_R;
+        // patch element of tap (ky, kx0): ((2 py + ky) * SP_PW + 2 px + kx0) * 4 halves; kx0 = 2 * ((s & 1) * 2 + fhalf)
+        const _Float16 *a0 = patch + ((size_t)(2 * py) * SP_PW + 2 * px + 2 * fhalf) * 4;
+        floatx16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SP_KS; ++s) {
+            const half8 a = *(const half8 *)(a0 + ((size_t)(s >> 1) * SP_PW + (s & 1) * 4) * 4);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wb[s][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, wb[s][1], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float bv = p.bias[j * 32 + frow];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                p0t[(size_t)row * 64 + j * 32 + frow] = (_Float16)fmaxf(acc[j][r] + bv, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- (a) the 16 x 16 p0 pixels this tile owns -> HBM, one 128-byte line per pixel --------------------------------------
+    _Float16 *p0 = (_Float16 *)p.p0 + (size_t)b * p.s0 * p.s0 * 64;
+    for (int i = tid; i < 16 * 16 * 8; i += 256) {
+        const int v = i & 7, pix = i >> 3;
+        const int ly = 1 + (pix >> 4), lx = 1 + (pix & 15);   // tile-local p0 coordinates (0 = the halo row / column)
+        const int gy = r0 + ly, gx = c0 + lx;
+        if (gy < p.s0 && gx < p.s0)
+            *(uint4v *)(p0 + ((size_t)gy * p.s0 + gx) * 64 + v * 8) = *(const uint4v *)(p0t + (size_t)(ly * SP_R + lx) * 64 + v * 8);
+    }
+    // ---- (b) maxpool 3 x 3 stride 2 pad 1 (padding = -inf: pixels outside p0 do not take part) ----------------------------
+    _Float16 *x1 = (_Float16 *)p.x1 + (size_t)b * p.s1 * p.s1 * 64;
+    for (int i = tid; i < SP_TP * SP_TP * 8; i += 256) {
+        const int v = i & 7, q = i >> 3;
+        const int qy = q >> 3, qx = q & 7;
+        const int oy = ty0 + qy, ox = tx0 + qx;
+        if (oy >= p.s1 || ox >= p.s1) continue;
+        half8 mx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx[e] = (_Float16)(-65504.0f);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ly = 2 * qy + dy, lx = 2 * qx + dx;          // tile-local p0 coordinates
+                const int gy = r0 + ly, gx = c0 + lx;
+                if ((unsigned)gy < (unsigned)p.s0 && (unsigned)gx < (unsigned)p.s0) {
+                    const half8 t = *(const half8 *)(p0t + (size_t)(ly * SP_R + lx) * 64 + v * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mx[e] = t[e] > mx[e] ? t[e] : mx[e];
+                }
+            }
+        *(half8 *)(x1 + ((size_t)oy * p.s1 + ox) * 64 + v * 8) = mx;
+    }
+}
+
+int launch_stem_pool(const StemPoolParams &p, void *stream) {
+    if (p.Kpad < SP_KS * 16 || !p.wgt_frag || !p.bias || p.s0 != (p.S - 7) / 2 + 1 || p.s1 != (p.s0 - 1) / 2 + 1) return -1;
+    const int tpr = (p.s1 + SP_TP - 1) / SP_TP;
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(p.B * tpr * tpr), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk
