@@ -302,7 +302,7 @@ def roofline(w, steps=3):
         try:                                              # fabric-side bytes of the same kernel sources, if measured
             t = json.load(open(pmc))
             if t.get("kernel_sources_sha256") == kernel_sources_sha256():
-                bk = t.get("by_kernel", {}).get("dw_xcorr_full_kernel") or t.get("by_kernel", {}).get("dw_xcorr_kernel")
+                bk = t.get("by_kernel", {}).get("dw_xcorr_tall_kernel") or t.get("by_kernel", {}).get("dw_xcorr_kernel")
                 if bk:
                     out["dw_xcorr"]["traffic"] = bk["hbm_bytes_per_launch_corrected"]
         except Exception:  # noqa: BLE001

@@ -629,6 +629,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
         p.buf_lds = (g_tune.buf_lds && ib < 2.0e9 && wb < 2.0e9) ? 1 : 0;
         p.a_stage = g_tune.a_stage;
+        p.res_nt = g_tune.res_nt;
         p.in_bytes = (unsigned)(ib < 4.0e9 ? ib : 0);
         p.w_bytes = (unsigned)(wb < 4.0e9 ? wb : 0);
     }
@@ -710,6 +711,7 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     L.pad = (signed char)p.pad; L.dil = (signed char)p.dil; L.relu = (signed char)p.relu; L.res_mode = (signed char)p.res_mode;
     L.ci_shift = (signed char)p.ci_shift;
     L.a_stage = (signed char)p.a_stage;
+    L.res_nt = (signed char)p.res_nt;
     // workgroup tile: the widest that still gives the 32 workgroups of an XCD a tile each per image
     L.cfg = p.Nst >= 512 ? 0 : (p.Nst >= 192 ? 1 : 2);
     // Short-K layers are dominated by the fixed cost of a tile (operand first touch, residual fetch, accumulator hand-over:
@@ -1714,6 +1716,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "ablate")) g_tune.ablate = value & 7;
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
+    else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
@@ -1745,7 +1748,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep},
+        {"seq_deep", &g_tune.seq_deep}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused},

@@ -135,19 +135,23 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
         }
 }
 
-// Full-height variant (round 3): workgroup = (32 channels) x (the WHOLE image of one batch item).  The banded kernel above
-// re-reads kh - 1 of every XC_BR + kh - 1 input rows (1.8x the input at 5-row bands: 25.3 MB fabric-side for 18.3 MB
-// algorithmic at B = 8) and its 480 small workgroups each pay a full load -> compute -> store latency chain.  Here every input
-// byte is read exactly once (29 x 29 x 32 channels = 54 KB of fp16 in LDS), 24 x B workgroups of 13 waves; a thread owns a
-// channel pair and a half-row strip as before and walks the output rows strip by strip.
+// Tall-band variant (round 3): workgroup = (64 channels) x (a band of `band` output rows: 13 of the 25 -> two bands per image).
+// The 5-row bands above re-read kh - 1 of every 9 input rows (1.8x the input: 25.3 MB fabric-side for 18.3 MB algorithmic at
+// B = 8) and their 480 small workgroups each pay a whole load -> compute -> store latency chain.  With 13-row bands the input
+// is read 1.14x (17 + 16 of 29 rows), every access is a full 128-byte line of 64 channels (a 32-channel variant halves the
+// LDS footprint but makes every line a shared, partially written one: measured 52 MB fabric-side), 24 x B workgroups of 13
+// waves; a thread owns a channel pair and ONE half-row strip, and all of its 16-byte loads are in flight before the first
+// LDS write.
 template <typename T, int XC_CH>
-__global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p) {
+__global__ __launch_bounds__(1024) void dw_xcorr_tall_kernel(const XcorrParams p, const int band) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     constexpr int VE = 16 / (int)sizeof(T);
     constexpr int VPP = XC_CH / VE;
-    const int c0 = blockIdx.x * XC_CH, b = blockIdx.y;
-    T *sx = (T *)xsm;                                // [H][W][XC_CH]
-    T *sk = sx + (size_t)p.H * p.W * XC_CH;          // [kh*kw][XC_CH]
+    const int c0 = blockIdx.x * XC_CH, i0 = blockIdx.y * band, b = blockIdx.z;
+    const int rows_out = min(band, p.Ho - i0);
+    const int rows_in = rows_out + p.kh - 1;
+    T *sx = (T *)xsm;                                // [rows_in][W][XC_CH]
+    T *sk = sx + (size_t)(band + p.kh - 1) * p.W * XC_CH;   // [kh*kw][XC_CH]
     const T *x = (const T *)p.x;
     const T *k = (const T *)p.k;
     const int nthr = blockDim.x;
@@ -157,10 +161,8 @@ __global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p
         const size_t g = ((size_t)b * p.kh * p.kw + tap) * p.Cs + c0 + q * VE;
         *(uint4 *)(sk + (size_t)tap * XC_CH + q * VE) = *(const uint4 *)(k + g);
     }
-    const int nvx = p.H * p.W * VPP;
-    const size_t xb = (size_t)b * p.H * p.W * p.Cs + c0;
-    // all of a thread's 16-byte loads are in flight before the first one is written to LDS (a load -> ds_write loop
-    // serialises one memory latency per iteration: 5 x ~2 us of the 13 us the banded kernel took)
+    const int nvx = rows_in * p.W * VPP;
+    const size_t xb = ((size_t)(b * p.H + i0) * p.W) * p.Cs + c0;      // the band's input rows are contiguous pixels
     constexpr int NLD = 6;
     for (int v0 = threadIdx.x; v0 < nvx; v0 += NLD * nthr) {
         uint4 r[NLD];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p
     const int strip = threadIdx.x / NCP, nstrip = nthr / NCP;
     const int wfirst = (p.Wo + 1) / 2;
     T *out = (T *)p.out;
-    for (int sidx = strip; sidx < 2 * p.Ho; sidx += nstrip) {
+    for (int sidx = strip; sidx < 2 * rows_out; sidx += nstrip) {
         const int ri = sidx >> 1, half = sidx & 1;
         const int j0 = half ? wfirst : 0;
         const int jn = half ? p.Wo - wfirst : wfirst;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p
 #pragma unroll
         for (int j = 0; j < XC_SW; ++j)
             if (j < jn) {
-                const size_t g = ((size_t)(b * p.Ho + ri) * p.Wo + j0 + j) * p.Cs + c0 + cp * 2;
+                const size_t g = ((size_t)(b * p.Ho + i0 + ri) * p.Wo + j0 + j) * p.Cs + c0 + cp * 2;
                 P2<T>::st(out + g, acc[j]);
             }
     }
@@ -227,20 +229,29 @@ __global__ __launch_bounds__(1024) void dw_xcorr_full_kernel(const XcorrParams p
 void xcorr_prepare() {
     static bool done = false;
     if (done) return;
-    (void)hipFuncSetAttribute((const void *)dw_xcorr_full_kernel<_Float16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void *)dw_xcorr_full_kernel<float, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_xcorr_tall_kernel<_Float16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_xcorr_tall_kernel<float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     done = true;
 }
 
 template <typename T>
-static bool launch_xcorr_full(const XcorrParams &p, hipStream_t s) {
-    constexpr int CH = 32;
-    const size_t lds = ((size_t)p.H * p.W + (size_t)p.kh * p.kw) * CH * sizeof(T);
-    if (lds > 150 * 1024 || p.C % CH != 0) return false;
+static bool launch_xcorr_tall(const XcorrParams &p, hipStream_t s) {
+    constexpr int CH = 64;
+    if (p.C % CH != 0) return false;
+    // as few bands as the LDS (<= 150 KB) and the thread count (one strip per thread, <= 1024) allow
+    int nb = 1;
+    for (;; ++nb) {
+        const int band = (p.Ho + nb - 1) / nb;
+        const size_t lds = ((size_t)(band + p.kh - 1) * p.W + (size_t)p.kh * p.kw) * CH * sizeof(T);
+        if ((lds <= 150 * 1024 && 2 * band * (CH / 2) <= 1024) || band == 1) break;
+    }
+    const int band = (p.Ho + nb - 1) / nb;
+    const size_t lds = ((size_t)(band + p.kh - 1) * p.W + (size_t)p.kh * p.kw) * CH * sizeof(T);
+    if (lds > 150 * 1024) return false;
     xcorr_prepare();                                 // (no-op after the first call; smk_create calls it before any capture)
-    int strips = 2 * p.Ho;                           // one (row, half) strip per thread group of CH / 2 threads, <= 1024 threads
+    int strips = 2 * band;
     if (strips * (CH / 2) > 1024) strips = 1024 / (CH / 2);
-    hipLaunchKernelGGL((dw_xcorr_full_kernel<T, CH>), dim3(p.C / CH, p.B), dim3(strips * (CH / 2)), lds, s, p);
+    hipLaunchKernelGGL((dw_xcorr_tall_kernel<T, CH>), dim3(p.C / CH, (p.Ho + band - 1) / band, p.B), dim3(strips * (CH / 2)), lds, s, p, band);
     return true;
 }
 
@@ -256,8 +267,8 @@ static void launch_xcorr_t(const XcorrParams &p, hipStream_t s) {
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
     if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % 64 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (g_tune.xc_full) {                                // the whole image of a 32-channel chunk per workgroup (default)
-        const bool ok = dtype == DT_F16 ? launch_xcorr_full<_Float16>(p, s) : launch_xcorr_full<float>(p, s);
+    if (g_tune.xc_full) {                                // tall bands of 64 channels (default)
+        const bool ok = dtype == DT_F16 ? launch_xcorr_tall<_Float16>(p, s) : launch_xcorr_tall<float>(p, s);
         if (ok) return hipGetLastError() == hipSuccess ? 0 : -4;
     }
     const bool c32 = g_tune.xc_ch == 32;

@@ -59,6 +59,7 @@ struct ConvParams {
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
     int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
     int a_stage;           // conv_wreg / conv_seq producers: 1 = activation rows global -> VGPR -> ds_write (A/B knob "a_stage")
+    int res_nt;            // conv_wreg / conv_seq: residual rows fetched non-temporally (A/B knob "res_nt")
     unsigned in_bytes, w_bytes;   // extents of the input tensor / weight pack for the SRDs
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
     // split-K across workgroups (NHWC epilogue): scratch for the f32 partial tiles and one arrival counter per
@@ -99,6 +100,7 @@ struct SeqLayer {
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
     signed char a_stage;   // see ConvParams::a_stage
     signed char kstag;     // 1: every workgroup starts its K loop at another K tile (see wreg_tile kt0)
+    signed char res_nt;    // 1: residual rows are fetched non-temporally (the tensor is dead after this layer)
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
@@ -135,7 +137,7 @@ struct Tuning {
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
     int xc_ch = 64;            // dw_xcorr, banded kernel: channels per workgroup (64 or 32)
     int stem_fused = 1;        // fp16: cvt_in + stem + maxpool as ONE launch (stem_pool_kernel); 0 = the three launches of rounds 1-2
-    int xc_full = 1;           // dw_xcorr: one workgroup = 32 channels x the whole image (every input byte read once); 0 = 5-row bands
+    int xc_full = 1;           // dw_xcorr: 64 channels x 13-row bands (two per image, input read 1.14x, full 128-byte lines); 0 = 5-row bands
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
@@ -153,6 +155,7 @@ struct Tuning {
                                // (1: short-K layers only -- the rule with two producer waves; 2: all, measured -1.7 % with four)
     int seq_kstag = 1;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
                                // weights fit the L2, 2 all)
+    int res_nt = 1;            // conv_wreg / conv_seq: residual rows fetched non-temporally (the block input is dead after the add): -0.6 % B=8, -0.8 % B=64, bit-identical
     int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
     int wreg_policy = 1;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer

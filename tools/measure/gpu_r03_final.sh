@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round 3, final code: full GPU suite, the driver's exact bench command (+ per-layer profile), the 200-step line, rocprofv3
+# kernel stats of the driver's command, PMC passes (separate runs, kernel-trace only) and the traffic summary tied to the
+# kernel sources (sha256) that bench.py checks.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/r03final
+O=$R/gpurun_out/r03final
+export SMK_GRAPH=1
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+timeout 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --profile-out $O/layers_b8.json > $O/bench_driver_cmd.json 2>/dev/null; echo "driver-cmd bench exit $?"
+timeout 300 python3 bench.py --steps 200 --warmup 20 --no-also --no-cpu-baseline > $O/bench_200steps.json 2>/dev/null; echo "200-step bench exit $?"
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/prof
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof -- python $R/bench.py --steps 20 --warmup 5 --prewarm-seconds 0.3 --no-cpu-baseline --no-also > $O/rocprof_bench.json 2> $O/rocprof.err
+echo "rocprof exit $?"
+find $O/prof -name "*kernel_trace.csv" -delete
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp "$f" $O/rocprofv3_kernel_stats.csv
+cd $R
+bash tools/measure/gpu_pmc.sh \
+  "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
+  "FETCH_SIZE TCC_HIT_sum SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
+  "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" 2>&1 | tail -40 > $O/pmc_tail.txt
+cp gpurun_out/pmc/pmc_by_kernel.json $O/pmc_by_kernel.json
+python tools/measure/pmc_traffic.py $O/pmc_by_kernel.json sharp_b8_f16 "profiles/r03f_pmc_by_kernel.json" > $O/pmc_traffic_sharp_b8_f16.json
+python - <<PY
+import json
+d=json.loads(open("$O/bench_driver_cmd.json").read().strip().splitlines()[-1])
+print("driver cmd:", d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["avg_launch_us"], d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"], d.get("also"))
+d=json.loads(open("$O/bench_200steps.json").read().strip().splitlines()[-1]); print("200 steps:", d["value"], d["ms_per_step"])
+t=json.load(open("$O/pmc_traffic_sharp_b8_f16.json")); print(json.dumps(t["by_kernel"], indent=0)[:900])
+PY

@@ -44,7 +44,7 @@ def one(name):
 
 out = {"workload": workload,
        "kernel_sources_sha256": kernel_sources_sha256(),
-       "by_kernel": {n: one(n) for n in ("conv_seq_kernel", "chain_mask_kernel", "dw_xcorr_full_kernel", "dw_xcorr_kernel") if one(n)},
+       "by_kernel": {n: one(n) for n in ("conv_seq_kernel", "chain_mask_kernel", "dw_xcorr_tall_kernel", "dw_xcorr_kernel") if one(n)},
        "source": "%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, tools/measure/gpu_pmc.sh)" % label,
        "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                      "WRITE_SIZE as reported (uncalibrated)",
