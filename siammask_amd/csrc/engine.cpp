@@ -1726,7 +1726,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;
     else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
-    else if (!strcmp(key, "xc_full")) g_tune.xc_full = value != 0;
+    else if (!strcmp(key, "xc_full")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "xc_full 0|1|2"); g_tune.xc_full = value; }
     else if (!strcmp(key, "stem_fused")) g_tune.stem_fused = value != 0;
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;

@@ -46,7 +46,7 @@ constexpr int XC_THREADS = 32 * XC_BR * 2;   // upper bound (64-channel workgrou
 
 // XC_CH = channels per workgroup (64 or 32): 32 doubles the number of workgroups, whose load / compute /
 // store phases then overlap better on a CU (this kernel is latency-, not bandwidth-limited at B=8)
-template <typename T, int XC_CH>
+template <typename T, int XC_CH, bool BATCH = false>
 __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     constexpr int VE = 16 / (int)sizeof(T);
@@ -62,26 +62,34 @@ __global__ __launch_bounds__(XC_THREADS) void dw_xcorr_kernel(const XcorrParams 
 
     const int nvx = rows_in * p.W * VPP;
     const int nthr = blockDim.x;
-    // all of a thread's 16-byte loads are in flight before the first LDS write (round 3: a load -> ds_write loop, which is
-    // what the compiler makes of the obvious form, serialises one memory latency per iteration -- 7 of them here)
-    constexpr int NLD = 8;
-    const size_t xb = ((size_t)(b * p.H + i0) * p.W) * p.Cs + c0;       // the band's rows are contiguous pixels
-    for (int v0 = threadIdx.x; v0 < nvx; v0 += NLD * nthr) {
-        uint4 r[NLD];
+    if (BATCH) {
+        // (measurement variant, xc_full = 2: all of a thread's 16-byte loads in flight before the first LDS write)
+        constexpr int NLD = 8;
+        const size_t xb = ((size_t)(b * p.H + i0) * p.W) * p.Cs + c0;       // the band's rows are contiguous pixels
+        for (int v0 = threadIdx.x; v0 < nvx; v0 += NLD * nthr) {
+            uint4 r[NLD];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int v = min(v0 + i * nthr, nvx - 1);
-            const int pix = v / VPP, q = v - pix * VPP;
-            r[i] = *(const uint4 *)(x + xb + (size_t)pix * p.Cs + q * VE);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int v = v0 + i * nthr;
-            if (v < nvx) {
+            for (int i = 0; i < NLD; ++i) {
+                const int v = (v0 + i * nthr < nvx) ? v0 + i * nthr : v0;
                 const int pix = v / VPP, q = v - pix * VPP;
-                *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = r[i];
+                r[i] = *(const uint4 *)(x + xb + (size_t)pix * p.Cs + q * VE);
             }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int v = v0 + i * nthr;
+                if (v < nvx) {
+                    const int pix = v / VPP, q = v - pix * VPP;
+                    *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = r[i];
+                }
+            }
+        }
+    } else {
+        for (int v = threadIdx.x; v < nvx; v += nthr) {
+            const int pix = v / VPP, q = v - pix * VPP;
+            const int r = pix / p.W, col = pix - r * p.W;
+            const size_t g = ((size_t)(b * p.H + i0 + r) * p.W + col) * p.Cs + c0 + q * VE;
+            *(uint4 *)(sx + (size_t)pix * XC_CH + q * VE) = *(const uint4 *)(x + g);
         }
     }
     const int nvk = p.kh * p.kw * VPP;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(1024) void dw_xcorr_tall_kernel(const XcorrParams p
         uint4 r[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {                  // (unconditional loads of a clamped index: a load under a branch
-            const int v = min(v0 + i * nthr, nvx - 1);   //  is waited for at the end of that branch)
+            const int v = (v0 + i * nthr < nvx) ? v0 + i * nthr : v0;   // (OOB: re-load the own first vector, an L1 hit; one shared address would serialise)
             const int pix = v / VPP, q = v - pix * VPP;
             r[i] = *(const uint4 *)(x + xb + (size_t)pix * p.Cs + q * VE);
         }
@@ -261,13 +269,14 @@ static void launch_xcorr_t(const XcorrParams &p, hipStream_t s) {
     dim3 grid(bands, p.C / CH, p.B);
     const size_t lds = ((size_t)(XC_BR + XC_KMAX - 1) * p.W + XC_KMAX * XC_KMAX) * CH * sizeof(T);
     // (CH/2 channel pairs) x (2*BR half-row strips) threads
-    hipLaunchKernelGGL((dw_xcorr_kernel<T, CH>), grid, dim3((CH / 2) * XC_BR * 2), lds, s, p);
+    if (g_tune.xc_full == 2) hipLaunchKernelGGL((dw_xcorr_kernel<T, CH, true>), grid, dim3((CH / 2) * XC_BR * 2), lds, s, p);
+    else hipLaunchKernelGGL((dw_xcorr_kernel<T, CH, false>), grid, dim3((CH / 2) * XC_BR * 2), lds, s, p);
 }
 
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream) {
     if (p.kh > XC_KMAX || p.kw > XC_KMAX || (p.Wo + 1) / 2 > XC_SW || p.C % 64 != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
-    if (g_tune.xc_full) {                                // tall bands of 64 channels (default)
+    if (g_tune.xc_full == 1) {                           // tall bands of 64 channels
         const bool ok = dtype == DT_F16 ? launch_xcorr_tall<_Float16>(p, s) : launch_xcorr_tall<float>(p, s);
         if (ok) return hipGetLastError() == hipSuccess ? 0 : -4;
     }

@@ -137,7 +137,10 @@ struct Tuning {
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
     int xc_ch = 64;            // dw_xcorr, banded kernel: channels per workgroup (64 or 32)
     int stem_fused = 1;        // fp16: cvt_in + stem + maxpool as ONE launch (stem_pool_kernel); 0 = the three launches of rounds 1-2
-    int xc_full = 1;           // dw_xcorr: 64 channels x 13-row bands (two per image, input read 1.14x, full 128-byte lines); 0 = 5-row bands
+    int xc_full = 0;           // dw_xcorr: 0 = 5-row bands x 64 channels (480 small workgroups, input read 1.8x: 13.9 us at B = 8, the
+                               // fastest -- default), 1 = 13-row bands (two per image, input read 1.14x, all loads of a thread in flight
+                               // before the first LDS write: 20.5 us -- fewer, fatter workgroups lose the overlap), 2 = 5-row bands with
+                               // the batched loads (21.5 us); rocprofv3, profiles/r03_dw_xcorr_variants.txt
     int buf_lds = 1;           // LDS-DMA through buffer resources instead of flat global addresses (measured
                                // faster: l3.0.ds 94 -> 76 us at B=8, profiles/r01_v5_ab_buf_lds.txt)
     int mask_overlap = 0;      // smk_step: mask head on a side stream beside decode + Refine (measured slower:
