@@ -157,7 +157,8 @@ int smk_set_graph_mode(smk_ctx *ctx, int enable);
  *   "stages" 0|2|3|4 (LDS ring depth)     "xcd_mode" 0|1|2 (tile -> XCD order)   "min_blocks_x16" (tile thresholds)
  *   "merge" 0|1 (independent convolutions share a launch)   "nt_store" 0|1 (streaming stores of the mask logits)
  *   "buf_lds" 0|1 (LDS-DMA through buffer resources; default 1)   "xc_ch" 64|32 (banded dw-xcorr: channels per workgroup; null)
- *   "stem_fused" 0|1 (fp16: frame -> conv1 + BN + ReLU -> p0 -> maxpool -> x1 as one launch, stem_pool_kernel; default 1)
+ *   "l1_fused" 0|1 (fp16: every layer1 Bottleneck as one launch, l1_block_kernel: weights in registers, conv1 / conv2 outputs in LDS;
+ *   default 1)   "stem_fused" 0|1 (fp16: frame -> conv1 + BN + ReLU -> p0 -> maxpool -> x1 as one launch, stem_pool_kernel; default 1)
  *   "xc_full" 0|1|2 (dw-xcorr: 0 = 5-row bands (default, fastest), 1 = 13-row bands (input read 1.14x instead of 1.8x, slower),
  *   2 = 5-row bands with batched loads (measurement))
  *   "prio" -1..3 (s_setprio of the consumer waves; measured null)   "mask_overlap" 0|1 (mask head on a graph side

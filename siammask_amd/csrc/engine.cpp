@@ -249,6 +249,7 @@ struct smk_ctx {
     std::vector<hipEvent_t> prof_pool;
     size_t prof_pool_next = 0;
     bool mask_join_pending = false;
+    bool prof_split_l1 = false;      // (reserved) per-layer attribution of layer1 while profiling
 };
 
 static const char *dtname(int dt) { return dt == DT_F16 ? "f16" : "f32"; }
@@ -1074,6 +1075,31 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             const int dil = (st == 2 && b > 0) ? 2 : 1;
             const int pad2 = dil > 1 ? dil : 2 - stride;
             const int so = stride == 2 ? s2 : sp;
+            if (st == 0 && c->dtype == DT_F16 && g_tune.l1_fused && !c->seq_on && !c->prof_split_l1) {
+                // layer1: the whole Bottleneck in one launch, weights in registers, intermediates in LDS (l1_block.hip)
+                auto f1 = c->conv.find(id + "c1"), f2 = c->conv.find(id + "c2"), f3 = c->conv.find(id + "c3");
+                auto fd = c->conv.find(id + "ds");
+                if (f1 == c->conv.end() || f2 == c->conv.end() || f3 == c->conv.end() || (b == 0 && fd == c->conv.end()))
+                    return fail(SMK_E_STATE, "internal: layer1 block %d not packed", b);
+                const bool last1 = b == STAGE_BLOCKS[0] - 1;
+                const char *on = last1 ? "p1" : ((b & 1) ? "b" : "a");
+                Act out1 = act(c, on, sp, sp, 256);
+                L1BlockParams lp;
+                memset(&lp, 0, sizeof(lp));
+                lp.x = cur.p; lp.y = out1.p;
+                lp.w1 = f1->second.w; lp.w2 = f2->second.w; lp.w3 = f3->second.w;
+                lp.b1 = f1->second.bias; lp.b2 = f2->second.bias; lp.b3 = f3->second.bias;
+                lp.K1pad = f1->second.Kpad; lp.K2pad = f2->second.Kpad; lp.K3pad = f3->second.Kpad;
+                if (b == 0) { lp.wd = fd->second.w; lp.bd = fd->second.bias; lp.Kdpad = fd->second.Kpad; }
+                lp.B = B; lp.S = sp; lp.Cin = cur.C;
+                const double px = (double)B * sp * sp;
+                const double flop = 2.0 * px * (64.0 * cur.C + 64.0 * 576 + 256.0 * 64 + (b == 0 ? 256.0 * 64 : 0.0));
+                const double bytes = px * (cur.C + 256.0) * 2 + (64.0 * cur.C + 64 * 576 + 256 * 64 + (b == 0 ? 256 * 64 : 0)) * 2;
+                ProfScope ps(c, s, (id + "block").c_str(), "l1_block", flop, bytes);
+                if (launch_l1_block(lp, s)) return fail(SMK_E_HIP, "l1_block launch failed: %s", hipGetErrorString(hipGetLastError()));
+                cur = out1;
+                continue;
+            }
             Act t1 = act(c, "t1", sp, sp, planes);
             Act t2 = act(c, "t2", so, so, planes);
             ConvOpt o1; o1.relu = 1;
@@ -1728,6 +1754,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "halo")) { if (value != 0 && value != 1 && value != 64 && value != 128) return fail(SMK_E_ARG, "halo 0|1|64|128"); g_tune.halo = value; }
     else if (!strcmp(key, "xc_full")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "xc_full 0|1|2"); g_tune.xc_full = value; }
     else if (!strcmp(key, "stem_fused")) g_tune.stem_fused = value != 0;
+    else if (!strcmp(key, "l1_fused")) g_tune.l1_fused = value != 0;
     else if (!strcmp(key, "xc_ch")) { if (value != 32 && value != 64) return fail(SMK_E_ARG, "xc_ch 32|64"); g_tune.xc_ch = value; }
     else if (!strcmp(key, "buf_lds")) g_tune.buf_lds = value != 0;
     else if (!strcmp(key, "a_stage")) g_tune.a_stage = value != 0;
@@ -1751,7 +1778,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_deep", &g_tune.seq_deep}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
-        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused},
+        {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
         {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)

@@ -1,0 +1,192 @@
+// l1_block.hip -- one ResNet layer1 Bottleneck (experiments/siammask_sharp/resnet.py:64-103,159) as ONE launch (fp16):
+//   conv1 1x1 (Cin -> 64) + BN + ReLU -> conv2 3x3 p1 (64 -> 64) + BN + ReLU -> conv3 1x1 (64 -> 256) + BN
+//   (+ shortcut: the block input, or for block 0 the 1x1 projection 64 -> 256 + BN) -> ReLU.
+//
+// Layer1 works on the 63 x 63 (search) / 31 x 31 (template) maps with 64 / 256 channels: 1 % of the network's FLOPs but
+// 16 MB tensors per layer at B = 8, three launches per block at 9-16 us each -- 100 us of the 0.68 ms step (15 %), 2.5-3x its
+// memory floor, and none of it arithmetic.  The round-2 attempt at fusing a block streamed the weights and ran one workgroup
+// per CU with a barrier per chunk: slower.  What is different here:
+//   * the WHOLE block's weights (16 + 36 + 16 KB) live in the four waves' REGISTERS for the lifetime of the workgroup
+//     (v_mfma_f32_16x16x32_f16 B-fragments: wave w owns output channels 16w..16w+15 of conv1 / conv2 and 64w..64w+63 of
+//     conv3): no weight traffic and no barrier inside a convolution;
+//   * a workgroup = one 8 x 8 output tile; the 10 x 10 halo of the block input is the ONLY activation read from memory
+//     (it also serves the residual add), conv1's and conv2's outputs stay in LDS as fp16 (exactly the rounding they get
+//     when they go through HBM), the 64 x 256 result leaves as full 512-byte pixel rows;
+//   * 76 KB of LDS and <= 256 VGPRs: two workgroups per CU, 512 of them at B = 8 -- the load of one tile overlaps the
+//     MFMAs of the other; four barriers per tile.
+// conv2's zero padding applies to conv1's OUTPUT: halo pixels outside the image are written as zeros, not relu(bias).
+#include <hip/hip_runtime.h>
+#include "smk_kernels.h"
+
+namespace smk {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+constexpr int LB_T = 8;                       // output tile side
+constexpr int LB_H = LB_T + 2;                // halo side (10)
+constexpr int LB_NH = LB_H * LB_H;            // halo pixels (100)
+constexpr int LB_NO = LB_T * LB_T;            // output pixels (64)
+constexpr int LB_TP = 64 * 2 + 16;            // LDS pitch of a 64-channel pixel row (144 B: conflict-free 16-row fragments)
+
+template <int CIN> struct LbLds {
+    static constexpr int XP = CIN * 2 + 16;                                  // pitch of a block-input pixel row
+    static constexpr int XS = LB_NH * XP;
+    static constexpr int T1 = LB_NH * LB_TP, T2 = LB_NO * LB_TP;
+    static constexpr int YP = 256 * 2 + 16;
+    static constexpr int YS = CIN == 256 ? 0 : LB_NO * YP;                   // block 0 stages its output separately
+    static constexpr int TOTAL = XS + T1 + T2 + YS;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p) {
+    constexpr bool FIRST = CIN == 64;
+    typedef LbLds<CIN> L;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[L::TOTAL];
+    unsigned char *xs = smem, *t1 = smem + L::XS, *t2 = t1 + L::T1, *ys = t2 + L::T2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, kq = lane >> 4;
+    const int tpr = (p.S + LB_T - 1) / LB_T;
+    const int b = blockIdx.x / (tpr * tpr);
+    const int tt = blockIdx.x - b * (tpr * tpr);
+    const int y0 = (tt / tpr) * LB_T, x0 = (tt - (tt / tpr) * tpr) * LB_T;
+
+    // ---- the block's weights: B fragments of v_mfma_f32_16x16x32_f16 (lane = (n = fr, k = 8 kq .. 8 kq + 7) of a 32-wide k-step)
+    constexpr int KS1 = CIN / 32;
+    const _Float16 *w1 = (const _Float16 *)p.w1, *w2 = (const _Float16 *)p.w2, *w3 = (const _Float16 *)p.w3;
+    half8 w1f[KS1], w2f[18], w3f[4][2], wdf[FIRST ? 4 : 1][2];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) w1f[ks] = *(const half8 *)(w1 + (size_t)(16 * wave + fr) * p.K1pad + ks * 32 + kq * 8);
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) w2f[ks] = *(const half8 *)(w2 + (size_t)(16 * wave + fr) * p.K2pad + ks * 32 + kq * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            w3f[j][ks] = *(const half8 *)(w3 + (size_t)((4 * wave + j) * 16 + fr) * p.K3pad + ks * 32 + kq * 8);
+            if constexpr (FIRST) wdf[j][ks] = *(const half8 *)((const _Float16 *)p.wd + (size_t)((4 * wave + j) * 16 + fr) * p.Kdpad + ks * 32 + kq * 8);
+        }
+    const float bias1 = p.b1[16 * wave + fr], bias2 = p.b2[16 * wave + fr];
+    float bias3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias3[j] = p.b3[(4 * wave + j) * 16 + fr] + (FIRST ? p.bd[(4 * wave + j) * 16 + fr] : 0.f);
+
+    // ---- the 10 x 10 halo of the block input -> LDS (pixels outside the image: zeros) -----------------------------------------
+    {
+        constexpr int VPP = CIN / 8;                          // 16-byte vectors per pixel
+        const _Float16 *x = (const _Float16 *)p.x + (size_t)b * p.S * p.S * CIN;
+        for (int v = tid; v < LB_NH * VPP; v += 256) {
+            const int px = v / VPP, q = v - px * VPP;
+            const int r = px / LB_H, c = px - r * LB_H;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            uint4v val = {0u, 0u, 0u, 0u};
+            if ((unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S)
+                val = *(const uint4v *)(x + ((size_t)gy * p.S + gx) * CIN + q * 8);
+            *(uint4v *)(xs + px * L::XP + q * 16) = val;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv1: 100 halo pixels (7 row blocks of 16) x this wave's 16 channels, K = CIN ---------------------------------------
+    for (int mt = 0; mt < 7; ++mt) {
+        int m = mt * 16 + fr;
+        m = m < LB_NH ? m : LB_NH - 1;
+        const unsigned char *a0 = xs + m * L::XP + kq * 16;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + ks * 64), w1f[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = mt * 16 + 4 * kq + i;
+            if (px < LB_NH) {
+                const int r = px / LB_H, c = px - r * LB_H;
+                const bool in_img = (unsigned)(y0 - 1 + r) < (unsigned)p.S && (unsigned)(x0 - 1 + c) < (unsigned)p.S;
+                *(_Float16 *)(t1 + px * LB_TP + (16 * wave + fr) * 2) = (_Float16)(in_img ? fmaxf(acc[i] + bias1, 0.f) : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2: 3 x 3 over the halo image, 64 output pixels (4 row blocks) x this wave's 16 channels, K = 9 x 64 -----------------
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = mt * 16 + fr, oy = m >> 3, ox = m & 7;
+        const unsigned char *a0 = t1 + (oy * LB_H + ox) * LB_TP + kq * 16;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            const int tap = ks >> 1, dy = tap / 3, dx = tap - 3 * dy;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + (dy * LB_H + dx) * LB_TP + (ks & 1) * 64), w2f[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(_Float16 *)(t2 + (mt * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc[i] + bias2, 0.f);
+    }
+    __syncthreads();
+
+    // ---- conv3 (+ the 1x1 projection shortcut of block 0): 64 pixels x this wave's 64 channels, K = 64; + residual; ReLU -----------
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = mt * 16 + fr;
+        const unsigned char *a0 = t2 + m * LB_TP + kq * 16;
+        const int cm = ((m >> 3) + 1) * LB_H + (m & 7) + 1;       // the same pixel in the halo image
+        floatx4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 a = *(const half8 *)(a0 + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3f[j][ks], acc[j], 0, 0, 0);
+        }
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 a = *(const half8 *)(xs + cm * L::XP + kq * 16 + ks * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wdf[j][ks], acc[j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = mt * 16 + 4 * kq + i;
+            const int cp = ((px >> 3) + 1) * LB_H + (px & 7) + 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (4 * wave + j) * 16 + fr;
+                float v = acc[j][i] + bias3[j];
+                if constexpr (FIRST) {
+                    *(_Float16 *)(ys + px * L::YP + n * 2) = (_Float16)fmaxf(v, 0.f);
+                } else {
+                    _Float16 *slot = (_Float16 *)(xs + cp * L::XP + n * 2);      // residual in, result out: same lane, same place
+                    v += (float)*slot;
+                    *slot = (_Float16)fmaxf(v, 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the 64 x 256 result: full 512-byte pixel rows to HBM ------------------------------------------------------------------
+    _Float16 *y = (_Float16 *)p.y + (size_t)b * p.S * p.S * 256;
+    for (int v = tid; v < LB_NO * 32; v += 256) {
+        const int px = v >> 5, q = v & 31;
+        const int gy = y0 + (px >> 3), gx = x0 + (px & 7);
+        if (gy < p.S && gx < p.S) {
+            const unsigned char *src = FIRST ? ys + px * L::YP + q * 16 : xs + (((px >> 3) + 1) * LB_H + (px & 7) + 1) * L::XP + q * 16;
+            *(uint4v *)(y + ((size_t)gy * p.S + gx) * 256 + q * 8) = *(const uint4v *)src;
+        }
+    }
+}
+
+int launch_l1_block(const L1BlockParams &p, void *stream) {
+    if (!p.x || !p.y || !p.w1 || !p.w2 || !p.w3 || (p.Cin != 64 && p.Cin != 256) || (p.Cin == 64 && !p.wd)) return -1;
+    if (p.K1pad < p.Cin || p.K2pad < 576 || p.K3pad < 64) return -1;
+    const int tpr = (p.S + LB_T - 1) / LB_T;
+    const dim3 grid(p.B * tpr * tpr), block(256);
+    if (p.Cin == 64) hipLaunchKernelGGL(l1_block_kernel<64>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(l1_block_kernel<256>, grid, block, 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk

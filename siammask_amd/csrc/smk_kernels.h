@@ -136,6 +136,7 @@ struct Tuning {
     int ksplit = 0;            // split-K across workgroups: 0 off (default: measured a net loss at B=8, +1 % at B=1,
                                // see pick_ksplit), 1 auto (long-K few-tile launches), 2 / 4 forced (tests)
     int xc_ch = 64;            // dw_xcorr, banded kernel: channels per workgroup (64 or 32)
+    int l1_fused = 1;          // fp16: every layer1 Bottleneck as ONE launch with its weights in registers (l1_block_kernel); 0 = 3-4 launches
     int stem_fused = 1;        // fp16: cvt_in + stem + maxpool as ONE launch (stem_pool_kernel); 0 = the three launches of rounds 1-2
     int xc_full = 0;           // dw_xcorr: 0 = 5-row bands x 64 channels (480 small workgroups, input read 1.8x: 13.9 us at B = 8, the
                                // fastest -- default), 1 = 13-row bands (two per image, input read 1.14x, all loads of a thread in flight
@@ -313,6 +314,14 @@ int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_stem_pool(const StemPoolParams &p, void *stream);
+// one layer1 Bottleneck as one launch (l1_block.hip); w* = plain [Npad][Kpad] f16 packs, wd / bd = the 1x1 projection shortcut of block 0
+struct L1BlockParams {
+    const void *x; void *y;
+    const void *w1, *w2, *w3, *wd;
+    const float *b1, *b2, *b3, *bd;
+    int B, S, Cin, K1pad, K2pad, K3pad, Kdpad;
+};
+int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
