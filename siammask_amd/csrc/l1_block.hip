@@ -74,29 +74,41 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
     for (int j = 0; j < 4; ++j) bias3[j] = p.b3[(4 * wave + j) * 16 + fr] + (FIRST ? p.bd[(4 * wave + j) * 16 + fr] : 0.f);
 
     // ---- the 10 x 10 halo of the block input -> LDS (pixels outside the image: zeros) -----------------------------------------
+    // All of a thread's 16-byte loads are issued before the first LDS write: with two workgroups per CU there is no third
+    // one to hide a load -> wait -> ds_write chain of 13 memory latencies behind.  (Unconditional loads of clamped
+    // coordinates + a select: a load under a branch is waited for at the end of that branch.)
     {
         constexpr int VPP = CIN / 8;                          // 16-byte vectors per pixel
+        constexpr int NLD = (LB_NH * VPP + 255) / 256;        // 13 (CIN = 256) / 4 (CIN = 64)
         const _Float16 *x = (const _Float16 *)p.x + (size_t)b * p.S * p.S * CIN;
-        for (int v = tid; v < LB_NH * VPP; v += 256) {
+        uint4v val[NLD];
+        bool ok[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int v = tid + i * 256;
+            v = v < LB_NH * VPP ? v : tid;                    // (beyond the tile: re-load the own first vector)
             const int px = v / VPP, q = v - px * VPP;
             const int r = px / LB_H, c = px - r * LB_H;
             const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            uint4v val = {0u, 0u, 0u, 0u};
-            if ((unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S)
-                val = *(const uint4v *)(x + ((size_t)gy * p.S + gx) * CIN + q * 8);
-            *(uint4v *)(xs + px * L::XP + q * 16) = val;
+            ok[i] = (unsigned)gy < (unsigned)p.S && (unsigned)gx < (unsigned)p.S;
+            const int cy = min(max(gy, 0), p.S - 1), cx = min(max(gx, 0), p.S - 1);
+            val[i] = *(const uint4v *)(x + ((size_t)cy * p.S + cx) * CIN + q * 8);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int v = tid + i * 256;
+            if (v < LB_NH * VPP) {
+                const int px = v / VPP, q = v - px * VPP;
+                *(uint4v *)(xs + px * L::XP + q * 16) = ok[i] ? val[i] : uint4v{0u, 0u, 0u, 0u};
+            }
         }
     }
     __syncthreads();
 
-    // ---- conv1: 100 halo pixels (7 row blocks of 16) x this wave's 16 channels, K = CIN ---------------------------------------
-    for (int mt = 0; mt < 7; ++mt) {
-        int m = mt * 16 + fr;
-        m = m < LB_NH ? m : LB_NH - 1;
-        const unsigned char *a0 = xs + m * L::XP + kq * 16;
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + ks * 64), w1f[ks], acc, 0, 0, 0);
+    // ---- conv1: 100 halo pixels (7 row blocks of 16) x this wave's 16 channels, K = CIN -----------------------------------------
+    // (row blocks in PAIRS: two independent accumulator chains, so that an MFMA does not wait for its predecessor's result)
+    auto c1_store = [&](int mt, const floatx4 &acc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = mt * 16 + 4 * kq + i;
@@ -106,22 +118,41 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
                 *(_Float16 *)(t1 + px * LB_TP + (16 * wave + fr) * 2) = (_Float16)(in_img ? fmaxf(acc[i] + bias1, 0.f) : 0.f);
             }
         }
+    };
+    for (int mt = 0; mt < 8; mt += 2) {
+        int m0 = mt * 16 + fr, m1 = m0 + 16;
+        m0 = m0 < LB_NH ? m0 : LB_NH - 1;
+        m1 = m1 < LB_NH ? m1 : LB_NH - 1;                      // (the eighth block does not exist: computed on clamped rows, not stored)
+        const unsigned char *a0 = xs + m0 * L::XP + kq * 16, *a1 = xs + m1 * L::XP + kq * 16;
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + ks * 64), w1f[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a1 + ks * 64), w1f[ks], acc1, 0, 0, 0);
+        }
+        c1_store(mt, acc0);
+        if (mt + 1 < 7) c1_store(mt + 1, acc1);
     }
     __syncthreads();
 
-    // ---- conv2: 3 x 3 over the halo image, 64 output pixels (4 row blocks) x this wave's 16 channels, K = 9 x 64 -----------------
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = mt * 16 + fr, oy = m >> 3, ox = m & 7;
-        const unsigned char *a0 = t1 + (oy * LB_H + ox) * LB_TP + kq * 16;
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    // ---- conv2: 3 x 3 over the halo image, 64 output pixels (4 row blocks, in pairs) x this wave's 16 channels, K = 9 x 64 ---------
+    for (int mt = 0; mt < 4; mt += 2) {
+        const int m0 = mt * 16 + fr, m1 = m0 + 16;
+        const unsigned char *a0 = t1 + ((m0 >> 3) * LB_H + (m0 & 7)) * LB_TP + kq * 16;
+        const unsigned char *a1 = t1 + ((m1 >> 3) * LB_H + (m1 & 7)) * LB_TP + kq * 16;
+        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 18; ++ks) {
             const int tap = ks >> 1, dy = tap / 3, dx = tap - 3 * dy;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + (dy * LB_H + dx) * LB_TP + (ks & 1) * 64), w2f[ks], acc, 0, 0, 0);
+            const int o = (dy * LB_H + dx) * LB_TP + (ks & 1) * 64;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + o), w2f[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a1 + o), w2f[ks], acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *(_Float16 *)(t2 + (mt * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc[i] + bias2, 0.f);
+        for (int i = 0; i < 4; ++i) {
+            *(_Float16 *)(t2 + (mt * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc0[i] + bias2, 0.f);
+            *(_Float16 *)(t2 + ((mt + 1) * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc1[i] + bias2, 0.f);
+        }
     }
     __syncthreads();
 
