@@ -94,6 +94,7 @@ struct PackedConv {
     void *w = nullptr;       // device [rows][Kpad] dtype
     void *w_halo = nullptr;  // same weights, K ordered (chunk, kh, kw, c in chunk) for conv3x3_halo_kernel (3x3 only)
     void *w_frag = nullptr;  // same weights in MFMA-fragment order for conv_wreg_kernel (f16 only)
+    void *w_frag16 = nullptr; // small packs (<= 256 rows, K <= 640: layer1): fragment order of v_mfma_f32_16x16x32_f16 (l1_block_kernel)
     float *bias = nullptr;   // device [rows] f32
     int N = 0;               // real output channels per group
     int rows = 0;            // total rows (all groups), multiple of NPAD_ALIGN
@@ -139,6 +140,21 @@ static int upload_frag_pack(PackedConv &pc, const std::vector<float> &rows_f32, 
     }
     HIPCHK(hipMalloc(&pc.w_frag, h.size() * 2));
     HIPCHK(hipMemcpy(pc.w_frag, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    if (pc.rows <= 256 && pc.Kpad <= 640 && pc.Kpad % 32 == 0 && pc.groups == 1) {
+        // [rows/16][Kpad/32][lane 0..63][8 halves] with lane = (n % 16) + 16 * ((k % 32) / 8), element e = k % 8
+        const int KS32 = pc.Kpad / 32;
+        std::vector<_Float16> g((size_t)pc.rows * pc.Kpad);
+        for (int n = 0; n < pc.rows; ++n) {
+            const float *src = rows_f32.data() + (size_t)n * pc.Kpad;
+            const size_t blk = (size_t)(n / 16) * KS32;
+            for (int k = 0; k < pc.Kpad; ++k) {
+                const int lane = (n % 16) + 16 * ((k % 32) / 8);
+                g[((blk + k / 32) * 64 + lane) * 8 + k % 8] = (_Float16)src[k];
+            }
+        }
+        HIPCHK(hipMalloc(&pc.w_frag16, g.size() * 2));
+        HIPCHK(hipMemcpy(pc.w_frag16, g.data(), g.size() * 2, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -1079,24 +1095,36 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
                 // layer1: the whole Bottleneck in one launch, weights in registers, intermediates in LDS (l1_block.hip)
                 auto f1 = c->conv.find(id + "c1"), f2 = c->conv.find(id + "c2"), f3 = c->conv.find(id + "c3");
                 auto fd = c->conv.find(id + "ds");
-                if (f1 == c->conv.end() || f2 == c->conv.end() || f3 == c->conv.end() || (b == 0 && fd == c->conv.end()))
-                    return fail(SMK_E_STATE, "internal: layer1 block %d not packed", b);
+                if (f1 == c->conv.end() || f2 == c->conv.end() || f3 == c->conv.end() || (b == 0 && fd == c->conv.end()) ||
+                    !f1->second.w_frag16 || !f2->second.w_frag16 || !f3->second.w_frag16 || (b == 0 && !fd->second.w_frag16))
+                    return fail(SMK_E_STATE, "internal: layer1 block %d not packed for l1_block_kernel", b);
                 const bool last1 = b == STAGE_BLOCKS[0] - 1;
                 const char *on = last1 ? "p1" : ((b & 1) ? "b" : "a");
                 Act out1 = act(c, on, sp, sp, 256);
                 L1BlockParams lp;
                 memset(&lp, 0, sizeof(lp));
                 lp.x = cur.p; lp.y = out1.p;
-                lp.w1 = f1->second.w; lp.w2 = f2->second.w; lp.w3 = f3->second.w;
+                lp.w1 = f1->second.w_frag16; lp.w2 = f2->second.w_frag16; lp.w3 = f3->second.w_frag16;
                 lp.b1 = f1->second.bias; lp.b2 = f2->second.bias; lp.b3 = f3->second.bias;
                 lp.K1pad = f1->second.Kpad; lp.K2pad = f2->second.Kpad; lp.K3pad = f3->second.Kpad;
-                if (b == 0) { lp.wd = fd->second.w; lp.bd = fd->second.bias; lp.Kdpad = fd->second.Kpad; }
+                if (b == 0) { lp.wd = fd->second.w_frag16; lp.bd = fd->second.bias; lp.Kdpad = fd->second.Kpad; }
                 lp.B = B; lp.S = sp; lp.Cin = cur.C;
                 const double px = (double)B * sp * sp;
                 const double flop = 2.0 * px * (64.0 * cur.C + 64.0 * 576 + 256.0 * 64 + (b == 0 ? 256.0 * 64 : 0.0));
                 const double bytes = px * (cur.C + 256.0) * 2 + (64.0 * cur.C + 64 * 576 + 256 * 64 + (b == 0 ? 256 * 64 : 0)) * 2;
+                const bool want_clk = getenv("SMK_L1_CLK") != nullptr && !c->graph_mode;
+                if (want_clk && !c->seq_clk) HIPCHK(hipMalloc((void **)&c->seq_clk, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
+                lp.clk = want_clk ? c->seq_clk : nullptr;
                 ProfScope ps(c, s, (id + "block").c_str(), "l1_block", flop, bytes);
                 if (launch_l1_block(lp, s)) return fail(SMK_E_HIP, "l1_block launch failed: %s", hipGetErrorString(hipGetLastError()));
+                if (want_clk) {
+                    unsigned long long h[6];
+                    HIPCHK(hipStreamSynchronize(s));
+                    HIPCHK(hipMemcpy(h, c->seq_clk, sizeof(h), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[l1 clk] %s workgroup 0: weights + halo in LDS %.2f | conv1 %.2f | conv2 %.2f | conv3 %.2f | stores %.2f | total %.2f us\n",
+                            id.c_str(), (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0,
+                            (h[5] - h[4]) / 100.0, (h[5] - h[0]) / 100.0);
+                }
                 cur = out1;
                 continue;
             }
@@ -1483,7 +1511,7 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf) hipFree(kv.second);
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->ks_part) hipFree(c->ks_part);
@@ -1523,7 +1551,7 @@ int smk_finalize_weights(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
     c->conv.clear();
     int rc = build_weights(c);
     if (rc) return rc;
@@ -1605,7 +1633,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
     c->conv.clear();
     c->finalized = false;
     for (int i = 0; i < h.n_conv; ++i) {
@@ -2030,6 +2058,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     TmpBufs tmp;
     tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
     if (pc.w_frag) tmp.v.push_back(pc.w_frag);
+    if (pc.w_frag16) tmp.v.push_back(pc.w_frag16);
     const size_t es = esize(dtype);
     CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
     CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C, 0};
@@ -2153,6 +2182,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
             CHK(upload_packed(pc, rows, bias, dtype));
             tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
             if (pc.w_frag) tmp.v.push_back(pc.w_frag);
+            if (pc.w_frag16) tmp.v.push_back(pc.w_frag16);
         }
         packs[i] = pc;
         outs[i].H = Ho; outs[i].W = Wo; outs[i].C = rup(op.g.Cout, 8);

@@ -7,7 +7,7 @@
 // memory floor, and none of it arithmetic.  The round-2 attempt at fusing a block streamed the weights and ran one workgroup
 // per CU with a barrier per chunk: slower.  What is different here:
 //   * the WHOLE block's weights (16 + 36 + 16 KB) live in the four waves' REGISTERS for the lifetime of the workgroup
-//     (v_mfma_f32_16x16x32_f16 B-fragments: wave w owns output channels 16w..16w+15 of conv1 / conv2 and 64w..64w+63 of
+//     (v_mfma_f32_16x16x32_f16 fragments: wave w owns output channels 16w..16w+15 of conv1 / conv2 and 64w..64w+63 of
 //     conv3): no weight traffic and no barrier inside a convolution;
 //   * a workgroup = one 8 x 8 output tile; the 10 x 10 halo of the block input is the ONLY activation read from memory
 //     (it also serves the residual add), conv1's and conv2's outputs stay in LDS as fp16 (exactly the rounding they get
@@ -52,26 +52,41 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
     const int b = blockIdx.x / (tpr * tpr);
     const int tt = blockIdx.x - b * (tpr * tpr);
     const int y0 = (tt / tpr) * LB_T, x0 = (tt - (tt / tpr) * tpr) * LB_T;
+    // (SMK_L1_CLK=1, eager runs: 100 MHz stamps of workgroup 0 at the phase boundaries -- measurement aid)
+    const bool clk = p.clk && blockIdx.x == 0 && tid == 0;
+    if (clk) p.clk[0] = wall_clock64();
 
-    // ---- the block's weights: B fragments of v_mfma_f32_16x16x32_f16 (lane = (n = fr, k = 8 kq .. 8 kq + 7) of a 32-wide k-step)
+    // ---- the block's weights: fragments of v_mfma_f32_16x16x32_f16 in fragment order (w_frag16: one contiguous KB per (16 output
+    // channels, 32 k) operand, lane = (n % 16) + 16 * ((k % 32) / 8)), every load a fully coalesced 1 KB wave instruction.
+    // The weights are the A operand and the activations the B operand (C^T = W x A^T), so that a lane ends up with FOUR
+    // CONSECUTIVE CHANNELS of one pixel -- 8-byte LDS accesses in the epilogues instead of four 2-byte ones.
     constexpr int KS1 = CIN / 32;
-    const _Float16 *w1 = (const _Float16 *)p.w1, *w2 = (const _Float16 *)p.w2, *w3 = (const _Float16 *)p.w3;
+    const uint4v *w1 = (const uint4v *)p.w1, *w2 = (const uint4v *)p.w2, *w3 = (const uint4v *)p.w3, *wd = (const uint4v *)p.wd;
+    const int k1s = p.K1pad >> 5, k2s = p.K2pad >> 5, k3s = p.K3pad >> 5, kds = p.Kdpad >> 5;
     half8 w1f[KS1], w2f[18], w3f[4][2], wdf[FIRST ? 4 : 1][2];
 #pragma unroll
-    for (int ks = 0; ks < KS1; ++ks) w1f[ks] = *(const half8 *)(w1 + (size_t)(16 * wave + fr) * p.K1pad + ks * 32 + kq * 8);
+    for (int ks = 0; ks < KS1; ++ks) w1f[ks] = __builtin_bit_cast(half8, w1[((size_t)wave * k1s + ks) * 64 + lane]);
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks) w2f[ks] = *(const half8 *)(w2 + (size_t)(16 * wave + fr) * p.K2pad + ks * 32 + kq * 8);
+    for (int ks = 0; ks < 18; ++ks) w2f[ks] = __builtin_bit_cast(half8, w2[((size_t)wave * k2s + ks) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            w3f[j][ks] = *(const half8 *)(w3 + (size_t)((4 * wave + j) * 16 + fr) * p.K3pad + ks * 32 + kq * 8);
-            if constexpr (FIRST) wdf[j][ks] = *(const half8 *)((const _Float16 *)p.wd + (size_t)((4 * wave + j) * 16 + fr) * p.Kdpad + ks * 32 + kq * 8);
+            w3f[j][ks] = __builtin_bit_cast(half8, w3[((size_t)(4 * wave + j) * k3s + ks) * 64 + lane]);
+            if constexpr (FIRST) wdf[j][ks] = __builtin_bit_cast(half8, wd[((size_t)(4 * wave + j) * kds + ks) * 64 + lane]);
         }
-    const float bias1 = p.b1[16 * wave + fr], bias2 = p.b2[16 * wave + fr];
-    float bias3[4];
+    // biases of this lane's four channels per 16-channel block (channel = block * 16 + 4 kq + i)
+    float b1v[4], b2v[4], b3v[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias3[j] = p.b3[(4 * wave + j) * 16 + fr] + (FIRST ? p.bd[(4 * wave + j) * 16 + fr] : 0.f);
+    for (int i = 0; i < 4; ++i) {
+        b1v[i] = p.b1[16 * wave + 4 * kq + i];
+        b2v[i] = p.b2[16 * wave + 4 * kq + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b3v[j][i] = p.b3[(4 * wave + j) * 16 + 4 * kq + i];
+            if constexpr (FIRST) b3v[j][i] += p.bd[(4 * wave + j) * 16 + 4 * kq + i];
+        }
+    }
 
     // ---- the 10 x 10 halo of the block input -> LDS (pixels outside the image: zeros) -----------------------------------------
     // All of a thread's 16-byte loads are issued before the first LDS write: with two workgroups per CU there is no third
@@ -105,56 +120,78 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
         }
     }
     __syncthreads();
+    if (clk) p.clk[1] = wall_clock64();
 
-    // ---- conv1: 100 halo pixels (7 row blocks of 16) x this wave's 16 channels, K = CIN -----------------------------------------
-    // (row blocks in PAIRS: two independent accumulator chains, so that an MFMA does not wait for its predecessor's result)
+    // ---- conv1: 100 halo pixels (7 row blocks of 16, in pairs: two independent accumulator chains) x this wave's 16 channels ------
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     auto c1_store = [&](int mt, const floatx4 &acc) {
+        const int px = mt * 16 + fr;                           // this lane's pixel of the block (the MFMA column)
+        if (px < LB_NH) {
+            const int r = px / LB_H, c = px - r * LB_H;
+            const bool in_img = (unsigned)(y0 - 1 + r) < (unsigned)p.S && (unsigned)(x0 - 1 + c) < (unsigned)p.S;
+            half4 h;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = mt * 16 + 4 * kq + i;
-            if (px < LB_NH) {
-                const int r = px / LB_H, c = px - r * LB_H;
-                const bool in_img = (unsigned)(y0 - 1 + r) < (unsigned)p.S && (unsigned)(x0 - 1 + c) < (unsigned)p.S;
-                *(_Float16 *)(t1 + px * LB_TP + (16 * wave + fr) * 2) = (_Float16)(in_img ? fmaxf(acc[i] + bias1, 0.f) : 0.f);
-            }
+            for (int i = 0; i < 4; ++i) h[i] = (_Float16)(in_img ? fmaxf(acc[i] + b1v[i], 0.f) : 0.f);
+            *(half4 *)(t1 + px * LB_TP + (16 * wave + 4 * kq) * 2) = h;
         }
     };
-    for (int mt = 0; mt < 8; mt += 2) {
-        int m0 = mt * 16 + fr, m1 = m0 + 16;
-        m0 = m0 < LB_NH ? m0 : LB_NH - 1;
-        m1 = m1 < LB_NH ? m1 : LB_NH - 1;                      // (the eighth block does not exist: computed on clamped rows, not stored)
-        const unsigned char *a0 = xs + m0 * L::XP + kq * 16, *a1 = xs + m1 * L::XP + kq * 16;
-        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // (row blocks FOUR at a time: four independent accumulator chains and four LDS fragment reads in flight per k-step -- with one
+    //  wave of the workgroup per SIMD nothing else hides the ds_read latency, which is what a phase of this kernel costs)
+    for (int mt = 0; mt < 8; mt += 4) {
+        const unsigned char *a[4];
+        floatx4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int m = (mt + u) * 16 + fr;
+            m = m < LB_NH ? m : LB_NH - 1;                     // (the eighth block does not exist: computed on clamped rows, not stored)
+            a[u] = xs + m * L::XP + kq * 16;
+            acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + ks * 64), w1f[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a1 + ks * 64), w1f[ks], acc1, 0, 0, 0);
+            half8 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = *(const half8 *)(a[u] + ks * 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[ks], f[u], acc[u], 0, 0, 0);
         }
-        c1_store(mt, acc0);
-        if (mt + 1 < 7) c1_store(mt + 1, acc1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (mt + u < 7) c1_store(mt + u, acc[u]);
     }
     __syncthreads();
+    if (clk) p.clk[2] = wall_clock64();
 
     // ---- conv2: 3 x 3 over the halo image, 64 output pixels (4 row blocks, in pairs) x this wave's 16 channels, K = 9 x 64 ---------
-    for (int mt = 0; mt < 4; mt += 2) {
-        const int m0 = mt * 16 + fr, m1 = m0 + 16;
-        const unsigned char *a0 = t1 + ((m0 >> 3) * LB_H + (m0 & 7)) * LB_TP + kq * 16;
-        const unsigned char *a1 = t1 + ((m1 >> 3) * LB_H + (m1 & 7)) * LB_TP + kq * 16;
-        floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const unsigned char *a[4];
+        floatx4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = u * 16 + fr;
+            a[u] = t1 + ((m >> 3) * LB_H + (m & 7)) * LB_TP + kq * 16;
+            acc[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < 18; ++ks) {
             const int tap = ks >> 1, dy = tap / 3, dx = tap - 3 * dy;
             const int o = (dy * LB_H + dx) * LB_TP + (ks & 1) * 64;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a0 + o), w2f[ks], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *)(a1 + o), w2f[ks], acc1, 0, 0, 0);
+            half8 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = *(const half8 *)(a[u] + o);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[ks], f[u], acc[u], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(_Float16 *)(t2 + (mt * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc0[i] + bias2, 0.f);
-            *(_Float16 *)(t2 + ((mt + 1) * 16 + 4 * kq + i) * LB_TP + (16 * wave + fr) * 2) = (_Float16)fmaxf(acc1[i] + bias2, 0.f);
+        for (int u = 0; u < 4; ++u) {
+            half4 h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = (_Float16)fmaxf(acc[u][i] + b2v[i], 0.f);
+            *(half4 *)(t2 + (u * 16 + fr) * LB_TP + (16 * wave + 4 * kq) * 2) = h;
         }
     }
     __syncthreads();
+    if (clk) p.clk[3] = wall_clock64();
 
     // ---- conv3 (+ the 1x1 projection shortcut of block 0): 64 pixels x this wave's 64 channels, K = 64; + residual; ReLU -----------
     for (int mt = 0; mt < 4; ++mt) {
@@ -168,35 +205,35 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
         for (int ks = 0; ks < 2; ++ks) {
             const half8 a = *(const half8 *)(a0 + ks * 64);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, w3f[j][ks], acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3f[j][ks], a, acc[j], 0, 0, 0);
         }
         if constexpr (FIRST) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const half8 a = *(const half8 *)(xs + cm * L::XP + kq * 16 + ks * 64);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wdf[j][ks], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdf[j][ks], a, acc[j], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = mt * 16 + 4 * kq + i;
-            const int cp = ((px >> 3) + 1) * LB_H + (px & 7) + 1;
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = (4 * wave + j) * 16 + 4 * kq;          // this lane's four channels of the block
+            half4 h;
+            if constexpr (FIRST) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = (4 * wave + j) * 16 + fr;
-                float v = acc[j][i] + bias3[j];
-                if constexpr (FIRST) {
-                    *(_Float16 *)(ys + px * L::YP + n * 2) = (_Float16)fmaxf(v, 0.f);
-                } else {
-                    _Float16 *slot = (_Float16 *)(xs + cp * L::XP + n * 2);      // residual in, result out: same lane, same place
-                    v += (float)*slot;
-                    *slot = (_Float16)fmaxf(v, 0.f);
-                }
+                for (int i = 0; i < 4; ++i) h[i] = (_Float16)fmaxf(acc[j][i] + b3v[j][i], 0.f);
+                *(half4 *)(ys + m * L::YP + n0 * 2) = h;
+            } else {
+                half4 *slot = (half4 *)(xs + cm * L::XP + n0 * 2);    // residual in, result out: same lane, same place
+                const half4 r = *slot;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = (_Float16)fmaxf(acc[j][i] + b3v[j][i] + (float)r[i], 0.f);
+                *slot = h;
             }
         }
     }
     __syncthreads();
+    if (clk) p.clk[4] = wall_clock64();
 
     // ---- the 64 x 256 result: full 512-byte pixel rows to HBM ------------------------------------------------------------------
     _Float16 *y = (_Float16 *)p.y + (size_t)b * p.S * p.S * 256;
@@ -208,11 +245,15 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
             *(uint4v *)(y + ((size_t)gy * p.S + gx) * 256 + q * 8) = *(const uint4v *)src;
         }
     }
+    if (clk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.clk[5] = wall_clock64();
+    }
 }
 
 int launch_l1_block(const L1BlockParams &p, void *stream) {
     if (!p.x || !p.y || !p.w1 || !p.w2 || !p.w3 || (p.Cin != 64 && p.Cin != 256) || (p.Cin == 64 && !p.wd)) return -1;
-    if (p.K1pad < p.Cin || p.K2pad < 576 || p.K3pad < 64) return -1;
+    if (p.K1pad < p.Cin || p.K2pad < 576 || p.K3pad < 64 || (p.K1pad | p.K2pad | p.K3pad | p.Kdpad) % 32) return -1;
     const int tpr = (p.S + LB_T - 1) / LB_T;
     const dim3 grid(p.B * tpr * tpr), block(256);
     if (p.Cin == 64) hipLaunchKernelGGL(l1_block_kernel<64>, grid, block, 0, (hipStream_t)stream, p);

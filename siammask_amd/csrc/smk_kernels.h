@@ -314,12 +314,14 @@ int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
 void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_stem_pool(const StemPoolParams &p, void *stream);
-// one layer1 Bottleneck as one launch (l1_block.hip); w* = plain [Npad][Kpad] f16 packs, wd / bd = the 1x1 projection shortcut of block 0
+// one layer1 Bottleneck as one launch (l1_block.hip); w* = f16 packs in 16x16x32-fragment order (PackedConv::w_frag16),
+// wd / bd = the 1x1 projection shortcut of block 0
 struct L1BlockParams {
     const void *x; void *y;
     const void *w1, *w2, *w3, *wd;
     const float *b1, *b2, *b3, *bd;
     int B, S, Cin, K1pad, K2pad, K3pad, Kdpad;
+    unsigned long long *clk;           // optional [6]: phase stamps of workgroup 0 (SMK_L1_CLK=1)
 };
 int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
