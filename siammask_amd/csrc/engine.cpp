@@ -1,6 +1,6 @@
 // engine.cpp -- host side of libsiammask_hip.so: context, BN folding + weight packing,
 // activation arena, the launch sequences for template / track / refine, hipGraph capture,
-// and the extern "C" ABI declared in include/siammask_hip.h.
+// and the extern "C" ABI declared in include/siammask_hip.h (product) and include/siammask_hip_test.h (tests, measurement).
 //
 // The network topology restated here (layer names, geometry) follows
 //   experiments/siammask_sharp/resnet.py:59-103,151-227   modified ResNet-50
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/siammask_hip.h"
+#include "../../include/siammask_hip_test.h"
 #include "smk_kernels.h"
 
 using namespace smk;
