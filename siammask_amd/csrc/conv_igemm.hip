@@ -1002,6 +1002,11 @@ int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream) 
     ConvParams &p = cb.p[0];
     if (p.out_mode != OUT_NCHW_F32 || p.groups > 1) return -1;
     const int tiles = ((p.M + 127) / 128) * ((p.Nst + 127) / 128);
+    // The two 128x128 tile bodies of a workgroup (threads 0-511 / 512-1023) share workgroup-wide barriers: both halves must
+    // run the same number of them, i.e. both must HAVE a tile (same K, ksplit 1).  An odd tile count would leave the last
+    // workgroup with one body only -- a path no shape of the network produces (3969 / 128 -> 32 column tiles: always even)
+    // and that is therefore refused here instead of relied upon; the caller falls back to the two separate launches.
+    if (tiles & 1) return 1;
     cb.start[0] = 0;
     for (int i = 1; i <= CONV_BATCH_MAX; ++i) cb.start[i] = tiles;
     p.ksplit = 1;

@@ -1338,10 +1338,14 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
             ConvBatch cb;
             cb.n = 1;
             cb.p[0] = c->deferred_mask;
-            c->have_deferred_mask = false;
             ProfScope ps(c, s, "refine_chain+mask3", "chain_mask", flop + c->deferred_mask_flop, cbytes + c->deferred_mask_bytes);
-            if (launch_chain_mask(rp, cb, s)) return fail(SMK_E_HIP, "chain_mask launch failed: %s", hipGetErrorString(hipGetLastError()));
-            return 0;
+            const int rc = launch_chain_mask(rp, cb, s);
+            if (rc == 0) {
+                c->have_deferred_mask = false;
+                return 0;
+            }
+            if (rc != 1) return fail(SMK_E_HIP, "chain_mask launch failed: %s", hipGetErrorString(hipGetLastError()));
+            ps.cancel();      // (odd tile count: the mask head keeps its own launch -- smk_step runs it after the chain)
         }
         ProfScope ps(c, s, "refine_chain", "refine_chain", flop, cbytes);
         if (launch_refine_chain(rp, s)) return fail(SMK_E_HIP, "refine_chain launch failed: %s", hipGetErrorString(hipGetLastError()));
