@@ -142,6 +142,24 @@ def test_conv_seq_repeated_launches_leave_the_counters_clean():
     _check(x, layers, a, "repeated")
 
 
+def test_conv_seq_measurement_build_gives_the_same_bits(monkeypatch, capfd):
+    """SMK_SEQ_CLK=2 selects conv_seq_kernel<4, 1> (phase stamps inside the first tile of every layer): a separate
+    instantiation that ships in the library -- it must compute exactly what the default build computes"""
+    ops = _ops()
+    rng = np.random.default_rng(61)
+    x = rng.uniform(-1, 1, size=(8, 128, 15, 15)).astype(np.float32)
+    layers = _bottleneck(rng, 128, 64, dil=1)
+    xd = torch.from_numpy(x).cuda()
+    a, _, _ = ops.conv_seq(xd, layers)
+    monkeypatch.setenv("SMK_SEQ_CLK", "2")
+    b, _, _ = ops.conv_seq(xd, layers)
+    monkeypatch.delenv("SMK_SEQ_CLK")
+    err = capfd.readouterr().err
+    assert "[seq clk2]" in err and "K loop" in err
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 # ---- failure must be loud and safe (the kernel needs all 256 workgroups resident at once) ---------------------------------
 def _model(B):
     from siammask_amd import synth
