@@ -108,8 +108,8 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
     for (int li = 0; li < a.n && alive; ++li) {
         const SeqLayer &L = a.L[li];
         const int cfg = L.cfg;
-        const int bn = (cfg == 0 || cfg == 3) ? 256 : ((cfg == 2 || cfg == 9) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
-        const int bm = (cfg == 3 || cfg == 4 || cfg == 9) ? 128 : 64;
+        const int bn = (cfg == 0 || cfg == 3 || cfg == 16 || cfg == 17) ? 256 : ((cfg == 2 || cfg == 9 || cfg == 18) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
+        const int bm = (cfg == 3 || cfg == 4 || cfg == 9 || cfg == 16) ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
         const int hw = L.Ho * L.Wo;
         const int tiles = ((hw + bm - 1) / bm) * tilesN;
@@ -140,6 +140,20 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 else if (cfg == 6) alive = wreg_tile<2, 2, 2, 3, 16 | 0x100, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 else if (cfg == 7) alive = wreg_tile<2, 2, 2, 3, 16 | 0x200, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 else if (cfg == 8) alive = wreg_tile<2, 2, 2, 3, 16 | 0x400, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+#ifdef SMK_SEQ_ABLATE
+                // (second set, built only with -DSMK_SEQ_ABLATE: 10 = MFMA + fragment reads + barriers (no operand refills), 11 = fragment
+                //  reads + barriers, 12 = barriers only, 13 = everything but the K-loop barriers, 14 = everything but the fragment reads)
+                else if (cfg == 10) alive = wreg_tile<2, 2, 2, 3, 16 | 0x300, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 11) alive = wreg_tile<2, 2, 2, 3, 16 | 0x700, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 12) alive = wreg_tile<2, 2, 2, 3, 16 | 0x1700, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 13) alive = wreg_tile<2, 2, 2, 3, 16 | 0x800, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 14) alive = wreg_tile<2, 2, 2, 3, 16 | 0x1000, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                // (15..18: the first version's issue order inside a k-step, the A/B arm of cfg 1 / 3 / 0 / 2)
+                else if (cfg == 15) alive = wreg_tile<2, 2, 2, 3, 16 | 0x2000, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (cfg == 16) alive = wreg_tile<4, 4, 1, 3, 16 | 0x2000, 1, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
+                else if (cfg == 17) alive = wreg_tile<2, 4, 1, 3, 16 | 0x2000, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
+                else if (cfg == 18) alive = wreg_tile<2, 1, 4, 3, 16 | 0x2000, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
+#endif
                 else alive = wreg_tile<2, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();

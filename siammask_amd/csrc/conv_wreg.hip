@@ -31,9 +31,10 @@ void conv_wreg_kernel(const ConvBatch cb) {
     wreg_tile<FM, WN, WK, NSTAGE, 0, 2, NPW>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
 }
 
-// measurement builds (smk_tune "ablate" = 1 no A refills, 2 no W refills, 4 no MFMA; results are wrong by construction)
+// measurement builds (smk_tune "ablate": bit 1 no A refills, 2 no W refills, 4 no MFMA, 8 no K-loop barriers, 16 no A-fragment
+// reads, 32 the first version's issue order (results right), 64 nothing removed; results are otherwise wrong by construction).  Four producer waves, like the production launches.
 template <int FM, int WN, int WK, int ABL>
-__global__ __launch_bounds__(384, (WregLds<FM, 3>::v <= 80 * 1024 ? 2 : 1))
+__global__ __launch_bounds__(512, 1)
 void conv_wreg_ablate_kernel(const ConvBatch cb) {
     const ConvParams &p = cb.p[0];
     constexpr int BM = 32 * FM, BN = 64 * WN;
@@ -41,7 +42,7 @@ void conv_wreg_ablate_kernel(const ConvBatch cb) {
     const int tilesN = (p.Nst + BN - 1) / BN;
     const int t = (int)blockIdx.x;
     const int tm = t / tilesN, tn = t - tm * tilesN;
-    wreg_tile<FM, WN, WK, 3, (ABL << 8)>(p, 0, tm * BM, p.M, tn * BN, smem);
+    wreg_tile<FM, WN, WK, 3, (ABL << 8), 2, 4>(p, 0, tm * BM, p.M, tn * BN, smem);
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
@@ -58,14 +59,21 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
     dim3 grid(total, 1, groups);
-    if constexpr ((FM == 2 && WN == 2 && WK == 2) || (WN == 4 && WK == 1))      // measurement builds: three tile shapes only
+    if constexpr ((WN == 2 && WK == 2) || (WN == 4 && WK == 1))      // measurement builds: four tile shapes only
     if (g_tune.ablate && cb.n == 1 && groups == 1) {
         switch (g_tune.ablate) {
-        case 1: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 1>), grid, dim3(384), 0, s, cb); break;
-        case 2: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 2>), grid, dim3(384), 0, s, cb); break;
-        case 3: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 3>), grid, dim3(384), 0, s, cb); break;
-        case 4: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 4>), grid, dim3(384), 0, s, cb); break;
-        default: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 7>), grid, dim3(384), 0, s, cb); break;
+        case 1: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 1>), grid, dim3(512), 0, s, cb); break;
+        case 2: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 2>), grid, dim3(512), 0, s, cb); break;
+        case 3: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 3>), grid, dim3(512), 0, s, cb); break;
+        case 4: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 4>), grid, dim3(512), 0, s, cb); break;
+        case 7: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 7>), grid, dim3(512), 0, s, cb); break;
+        case 8: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 8>), grid, dim3(512), 0, s, cb); break;
+        case 16: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 16>), grid, dim3(512), 0, s, cb); break;
+        case 32: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 32>), grid, dim3(512), 0, s, cb); break;
+        case 64: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 64>), grid, dim3(512), 0, s, cb); break;
+        case 11: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 11>), grid, dim3(512), 0, s, cb); break;
+        case 27: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 27>), grid, dim3(512), 0, s, cb); break;
+        default: hipLaunchKernelGGL((conv_wreg_ablate_kernel<FM, WN, WK, 23>), grid, dim3(512), 0, s, cb); break;
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }

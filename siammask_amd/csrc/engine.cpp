@@ -1772,7 +1772,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
-    else if (!strcmp(key, "ablate")) g_tune.ablate = value & 7;
+    else if (!strcmp(key, "ablate")) g_tune.ablate = value & 127;
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
@@ -2206,7 +2206,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         SeqLayer L;
         if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
         if (op.cfg >= 0) {
-            if (op.cfg > 9) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..9");
+            if (op.cfg > 18) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..9 (10..18: -DSMK_SEQ_ABLATE builds)");
             L.cfg = (signed char)op.cfg;
         }
         if (op.kstag >= 0) L.kstag = (signed char)(op.kstag != 0);

@@ -18,6 +18,7 @@
 // CU that implies.  Build: hipcc -O3 --offload-arch=gfx950 tools/kloop_skeleton.hip -o /tmp/kloop_skeleton
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#pragma clang diagnostic ignored "-Wunused-value"
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -28,15 +29,16 @@ struct Cfg { int nc, np, bm, bn, tiles, look; };
 
 // WPT = weight instructions per consumer wave per K tile, APT = activation instructions per producer wave per K tile,
 // MPT = MFMAs per consumer wave per K tile, LOOK = tiles in flight
-template <int WPT, int APT, int MPT, int LOOK, int MAXT>
-__global__ __launch_bounds__(MAXT) void kloop(const char *src, unsigned src_bytes, int nc, int np, int tiles, float *sink) {
+template <int WPT, int APT, int MPT, int LOOK, int MAXT, int full_a>
+__global__ __launch_bounds__(MAXT) void kloop(const char *src, unsigned src_bytes, int nc, int np, int tiles, float *sink, int wshare) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, src_bytes, 0x00020000);
     const unsigned region = 2048u * 1024u;
     if (wave < nc) {
         // ---- consumer: W fragments LOOK tiles ahead in a register ring, MFMAs on them, A fragments from LDS
-        unsigned off = (((blockIdx.x * 16 + wave) * 4099u) % 2048u) * 1024u + lane * 16;
+        // (wshare: every workgroup streams the SAME weight region, like the CUs of a layer do)
+        unsigned off = ((((wshare ? 0 : blockIdx.x * 16) + wave) * 4099u) % 2048u) * 1024u + lane * 16;
         auto next = [&]() { const unsigned o = off; off = (off + 64 * 1024) & (region - 1); return (int)o; };
         uint4v w[LOOK][WPT];
 #pragma unroll
@@ -53,12 +55,28 @@ __global__ __launch_bounds__(MAXT) void kloop(const char *src, unsigned src_byte
         for (int t0 = 0; t0 < tiles; t0 += LOOK) {
 #pragma unroll
             for (int t = 0; t < LOOK; ++t) {
-                half8 a0 = *(const half8 *)(la + ((t0 + t) & 3) * 8192);
-                half8 a1 = *(const half8 *)(la + ((t0 + t) & 3) * 8192 + 4096);
+                if constexpr (!full_a) {
+                    half8 a0 = *(const half8 *)(la + ((t0 + t) & 3) * 8192);
+                    half8 a1 = *(const half8 *)(la + ((t0 + t) & 3) * 8192 + 4096);
 #pragma unroll
-                for (int m = 0; m < MPT; ++m) {
-                    const half8 b = __builtin_bit_cast(half8, w[t][m % WPT]);
-                    acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16((m & 1) ? a1 : a0, b, acc[m & 3], 0, 0, 0);
+                    for (int m = 0; m < MPT; ++m) {
+                        const half8 b = __builtin_bit_cast(half8, w[t][m % WPT]);
+                        acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16((m & 1) ? a1 : a0, b, acc[m & 3], 0, 0, 0);
+                    }
+                } else {
+                    // the real kernel's LDS traffic: one A fragment (1 KB wave read) per TWO MFMAs (a wave's 64 columns = two
+                    // 32-column blocks), fragments fetched two MFMA pairs ahead
+                    half8 af[MPT / 2];
+#pragma unroll
+                    for (int m = 0; m < MPT / 2; ++m) {       // row block m / 4, k-step m % 4; the kernel's 16-byte-slot swizzle (conflict-free)
+                        const int row = (m >> 2) * 32 + (lane & 31), slot = ((m & 3) * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+                        af[m] = *(const half8 *)(smem + ((t0 + t) & 3) * 8192 + ((row * 128) & 8191) + slot * 16);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MPT; ++m) {
+                        const half8 b = __builtin_bit_cast(half8, w[t][m % WPT]);
+                        acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m >> 1], b, acc[m & 3], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < WPT; ++j) w[t][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, next(), 0, 0);
@@ -102,16 +120,16 @@ __global__ __launch_bounds__(MAXT) void kloop(const char *src, unsigned src_byte
     }
 }
 
-template <int WPT, int APT, int MPT, int LOOK>
-static double time_it(const char *src, unsigned bytes, const Cfg &c, float *sink) {
+template <int WPT, int APT, int MPT, int LOOK, int FA>
+static double time_it(const char *src, unsigned bytes, const Cfg &c, float *sink, int wshare) {
     const int threads = 64 * (c.nc + c.np);
     // registers: the weight ring + 64 accumulators must fit the per-wave budget (256 with <= 8 waves, 128 with 16)
     if (WPT * LOOK * 4 + 64 + 24 > (threads <= 512 ? 250 : 126)) return 0.0;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() {
-        if (threads <= 512) hipLaunchKernelGGL((kloop<WPT, APT, MPT, LOOK, 512>), dim3(256), dim3(threads), 40 * 1024, 0, src, bytes, c.nc, c.np, c.tiles, sink);
-        else hipLaunchKernelGGL((kloop<WPT, APT, MPT, LOOK, 1024>), dim3(256), dim3(threads), 40 * 1024, 0, src, bytes, c.nc, c.np, c.tiles, sink);
+        if (threads <= 512) hipLaunchKernelGGL((kloop<WPT, APT, MPT, LOOK, 512, FA>), dim3(256), dim3(threads), 40 * 1024, 0, src, bytes, c.nc, c.np, c.tiles, sink, wshare);
+        else hipLaunchKernelGGL((kloop<WPT, APT, MPT, LOOK, 1024, FA>), dim3(256), dim3(threads), 40 * 1024, 0, src, bytes, c.nc, c.np, c.tiles, sink, wshare);
     };
     launch();
     hipEventRecord(e0);
@@ -126,8 +144,8 @@ static double time_it(const char *src, unsigned bytes, const Cfg &c, float *sink
 
 #define CASE(WPT_, APT_, MPT_)                                                                            \
     if (wpt == WPT_ && apt == APT_ && mpt == MPT_) {                                                      \
-        us2 = time_it<WPT_, APT_, MPT_, 2>(src, bytes, c, sink);                                          \
-        us4 = time_it<WPT_, APT_, MPT_, 4>(src, bytes, c, sink);                                          \
+        us2 = full_a ? time_it<WPT_, APT_, MPT_, 2, 1>(src, bytes, c, sink, wshare) : time_it<WPT_, APT_, MPT_, 2, 0>(src, bytes, c, sink, wshare); \
+        us4 = full_a ? time_it<WPT_, APT_, MPT_, 4, 1>(src, bytes, c, sink, wshare) : time_it<WPT_, APT_, MPT_, 4, 0>(src, bytes, c, sink, wshare); \
         done = true;                                                                                      \
     }
 
@@ -139,6 +157,8 @@ int main() {
     printf("%-9s %3s %3s | W/wave A/wave MFMA/wave |  look2 us   GB/s/CU  MFMA%% |  look4 us   GB/s/CU  MFMA%%\n", "tile", "NC", "NP");
     const int shapes[4][2] = {{64, 128}, {64, 256}, {128, 128}, {128, 256}};
     const int splits[6][2] = {{4, 4}, {4, 8}, {8, 4}, {8, 8}, {4, 12}, {8, 12}};
+    for (int wshare = 0; wshare < 2; ++wshare)
+    for (int full_a = 0; full_a < 2; ++full_a)
     for (auto &sh : shapes)
         for (auto &sp : splits) {
             Cfg c{sp[0], sp[1], sh[0], sh[1], 2000, 2};
@@ -153,7 +173,7 @@ int main() {
             CASE(8, 1, 16) CASE(8, 2, 16) CASE(8, 2, 32) CASE(8, 4, 32)
             if (!done) { printf("%3dx%-5d %3d %3d | (no instantiation for W %d A %d MFMA %d)\n", sh[0], sh[1], c.nc, c.np, wpt, apt, mpt); continue; }
             const double kb = wkb + akb, ideal = mf * 32.0 / 4.0 / 2.4e3;      // MFMA time of the tile on 4 SIMDs at 2.4 GHz, us
-            printf("%3dx%-5d %3d %3d | %5d %6d %9d | %8.3f %9.1f %6.1f | %8.3f %9.1f %6.1f\n", sh[0], sh[1], c.nc, c.np, wpt, apt, mpt, us2,
+            printf("%-12s %3dx%-5d %3d %3d | %5d %6d %9d | %8.3f %9.1f %6.1f | %8.3f %9.1f %6.1f\n", wshare ? (full_a ? "fullA/sameW" : "2frag/sameW") : (full_a ? "fullA" : "2frag"), sh[0], sh[1], c.nc, c.np, wpt, apt, mpt, us2,
                    us2 > 0 ? kb * 1024 / us2 / 1e3 : 0.0, us2 > 0 ? 100.0 * ideal / us2 : 0.0, us4, us4 > 0 ? kb * 1024 / us4 / 1e3 : 0.0,
                    us4 > 0 ? 100.0 * ideal / us4 : 0.0);
             fflush(stdout);
