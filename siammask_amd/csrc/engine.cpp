@@ -869,10 +869,14 @@ static int seq_health(smk_ctx *c) {
 }
 
 static bool seq_wanted(const smk_ctx *c, int B) {
-    // measured (tools/measure/gpu_seq_ab.py, profiles/r02_seq_ab.txt): B = 8 (one image per XCD) x1.03-1.04 on the whole
-    // step; B = 16 x0.85, B = 64 x0.79 (two / eight images per team in sequence on 64-row tiles lose to the
-    // chip-wide 128/256-row tiles) -> on for one image per XCD only
-    return g_tune.seq && c->seq_grid > 0 && c->dtype == DT_F16 && B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch;
+    // Image b runs on XCD b % 8, so the sequence pays when the XCDs are (nearly) all busy and evenly loaded.  Measured with
+    // the sequence forced on for every batch size against the per-launch path, same process (tools/measure/gpu_seq_batch_sweep.py,
+    // profiles/r03_seq_batch_sweep.txt): B = 6 / 7 / 8 x1.02 / 1.05 / 1.10, B = 16 x1.07, B = 24 x1.02; B <= 4 x0.85-0.91 (idle
+    // XCDs: the per-launch kernels spread an image over the chip), B = 5 and 12 x1.00, B = 10 x0.97 (two XCDs run two images),
+    // B = 32 x0.95 (four images in sequence on 64-row tiles lose to the chip-wide 128 / 256-row tiles).
+    if (!g_tune.seq || c->seq_grid <= 0 || c->dtype != DT_F16) return false;
+    if (B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch) return true;
+    return B % 8 == 0 && B <= g_tune.seq_mult_max;
 }
 
 // conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
@@ -1780,6 +1784,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
+    else if (!strcmp(key, "seq_mult_max")) { if (value < 0) return fail(SMK_E_ARG, "seq_mult_max >= 0"); g_tune.seq_mult_max = value; }
     else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;
@@ -1810,7 +1815,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
-        {"seq_max_batch", &g_tune.seq_max_batch}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
+        {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
         {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};

@@ -484,6 +484,41 @@ def test_persistent_sequences_and_tail_fusion_are_what_runs_at_b8():
         assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, k
 
 
+@pytest.mark.parametrize("B,expect_seq", [(4, False), (6, True), (7, True), (12, False), (16, True), (24, True), (32, False)])
+def test_which_batches_run_the_persistent_sequence(B, expect_seq):
+    """engine.cpp seq_wanted (profiles/r03_seq_batch_sweep.txt): the sequence runs where the XCDs are evenly loaded -- B = 6..8, 16, 24 --
+    and nowhere else; where it runs, several images per XCD in turn (B = 16, 24) or idle XCDs (B = 6, 7) give the per-launch path's outputs
+    up to fp16 summation order, and the device error flag stays 0."""
+    from siammask_amd import _lib
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=11)).cuda()
+    x = torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=11)).cuda()
+    twh = torch.tensor([[60.0, 80.0]] * B, dtype=torch.float64).cuda()
+
+    def run(**knobs):
+        _lib.tune(**knobs)
+        m = _model("sharp", "synthetic_damped", "f16", True, max_batch=B)
+        m.template(z)
+        out = {k: v.clone() for k, v in m.track_step(x, twh, refine=True).items() if v is not None}
+        m.profile(True)
+        m.track_step(x, twh, refine=True)
+        recs = m.profile_dump()
+        m.profile(False)
+        torch.cuda.synchronize()
+        return out, [r["kernel"].split("<")[0] for r in recs], m.seq_status()
+
+    try:
+        on, kernels, (grid, err) = run(seq=1)
+        assert err == 0
+        assert kernels.count("conv_seq") == (1 if expect_seq else 0), (B, kernels)
+        if expect_seq:
+            off, kernels_off, _ = run(seq=0)
+            assert kernels_off.count("conv_seq") == 0
+            for k in ("cls", "loc", "mask", "refine"):
+                assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, (B, k)
+    finally:
+        _lib.tune(seq=1)
+
+
 def test_producer_variants_bit_equal_end_to_end():
     """smk_tune a_stage (activation rows of conv_wreg / conv_seq through registers instead of LDS-DMA) and npw (two or four
     producer waves) change the data path of the producers only: the fused B = 8 frame step (persistent sequences on) must
