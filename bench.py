@@ -44,6 +44,7 @@ WORKLOADS = {
     # name: (variant, batch per GPU, dtype, refine)
     "sharp_b8_f16": ("sharp", 8, "f16", True),      # BASELINE configs[2] / configs[3]
     "sharp_b1_f16": ("sharp", 1, "f16", True),
+    "sharp_b16_f16": ("sharp", 16, "f16", True),    # two streams per XCD in the persistent sequence
     "sharp_b64_f16": ("sharp", 64, "f16", True),    # configs[4] regime (per GPU)
     "sharp_b8_f32": ("sharp", 8, "f32", True),
     "base_b1_f32": ("base", 1, "f32", False),       # BASELINE configs[1]
@@ -507,7 +508,7 @@ def main():
 
     also = {}
     if rank == 0 and world == 1 and not args.no_also and not args.stub:
-        for name in ("sharp_b8_f32", "base_b1_f32", "sharp_b1_f16", "sharp_b64_f16"):
+        for name in ("sharp_b8_f32", "base_b1_f32", "sharp_b1_f16", "sharp_b16_f16", "sharp_b64_f16"):
             if name == args.workload:
                 continue
             try:
