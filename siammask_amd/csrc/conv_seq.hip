@@ -135,13 +135,13 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 else if (cfg == 9) alive = wreg_tile<4, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
                 // (measurement variant: 64x128 with a 5-deep activation ring and the weight fragments FOUR K tiles ahead)
                 else if (cfg == 5) alive = wreg_tile<2, 2, 2, 5, 16, 4, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
-                // (measurement variants of the 64x128 tile, results wrong by construction: 6 = activation tiles never refilled,
+#ifdef SMK_MEASURE
+                // (measurement variants of the 64x128 tile, only in a library built with `make MEASURE=1`; results wrong by construction: 6 = activation tiles never refilled,
                 //  7 = weight fragments never refilled, 8 = no MFMA -- which stream sets the K-tile time inside a sequence?)
                 else if (cfg == 6) alive = wreg_tile<2, 2, 2, 3, 16 | 0x100, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 else if (cfg == 7) alive = wreg_tile<2, 2, 2, 3, 16 | 0x200, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 else if (cfg == 8) alive = wreg_tile<2, 2, 2, 3, 16 | 0x400, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
-#ifdef SMK_SEQ_ABLATE
-                // (second set, built only with -DSMK_SEQ_ABLATE: 10 = MFMA + fragment reads + barriers (no operand refills), 11 = fragment
+                // (second set: 10 = MFMA + fragment reads + barriers (no operand refills), 11 = fragment
                 //  reads + barriers, 12 = barriers only, 13 = everything but the K-loop barriers, 14 = everything but the fragment reads)
                 else if (cfg == 10) alive = wreg_tile<2, 2, 2, 3, 16 | 0x300, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 else if (cfg == 11) alive = wreg_tile<2, 2, 2, 3, 16 | 0x700, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);

@@ -31,7 +31,8 @@ void conv_wreg_kernel(const ConvBatch cb) {
     wreg_tile<FM, WN, WK, NSTAGE, 0, 2, NPW>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
 }
 
-// measurement builds (smk_tune "ablate": bit 1 no A refills, 2 no W refills, 4 no MFMA, 8 no K-loop barriers, 16 no A-fragment
+#ifdef SMK_MEASURE
+// measurement builds, only in a library built with `make MEASURE=1` (smk_tune "ablate": bit 1 no A refills, 2 no W refills, 4 no MFMA, 8 no K-loop barriers, 16 no A-fragment
 // reads, 32 the first version's issue order (results right), 64 nothing removed; results are otherwise wrong by construction).  Four producer waves, like the production launches.
 template <int FM, int WN, int WK, int ABL>
 __global__ __launch_bounds__(512, 1)
@@ -44,6 +45,7 @@ void conv_wreg_ablate_kernel(const ConvBatch cb) {
     const int tm = t / tilesN, tn = t - tm * tilesN;
     wreg_tile<FM, WN, WK, 3, (ABL << 8), 2, 4>(p, 0, tm * BM, p.M, tn * BN, smem);
 }
+#endif
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
 template <int FM, int WN, int WK>
@@ -59,6 +61,7 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
     dim3 grid(total, 1, groups);
+#ifdef SMK_MEASURE
     if constexpr ((WN == 2 && WK == 2) || (WN == 4 && WK == 1))      // measurement builds: four tile shapes only
     if (g_tune.ablate && cb.n == 1 && groups == 1) {
         switch (g_tune.ablate) {
@@ -77,6 +80,7 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
         }
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
+#endif
     if (g_tune.npw == 4) {
         if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
         else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);

@@ -1776,7 +1776,13 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
     else if (!strcmp(key, "seq")) g_tune.seq = value != 0;
-    else if (!strcmp(key, "ablate")) g_tune.ablate = value & 127;
+    else if (!strcmp(key, "ablate")) {
+#ifdef SMK_MEASURE
+        g_tune.ablate = value & 127;
+#else
+        if (value) return fail(SMK_E_ARG, "ablate: the measurement kernels are only in a library built with `make MEASURE=1`");
+#endif
+    }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
@@ -1808,6 +1814,14 @@ int smk_tune(const char *key, int value) {
 
 int smk_tune_get(const char *key, int *value) {
     if (!key || !value) return fail(SMK_E_ARG, "smk_tune_get: null argument");
+    if (!strcmp(key, "measure_build")) {              // 1: built with `make MEASURE=1` (the K-loop ablation kernels are present)
+#ifdef SMK_MEASURE
+        *value = 1;
+#else
+        *value = 0;
+#endif
+        return 0;
+    }
     static const struct { const char *name; int *slot; } knobs[] = {
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
@@ -2211,7 +2225,12 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         SeqLayer L;
         if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
         if (op.cfg >= 0) {
-            if (op.cfg > 18) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..9 (10..18: -DSMK_SEQ_ABLATE builds)");
+#ifdef SMK_MEASURE
+            if (op.cfg > 18) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..18");
+#else
+            if (op.cfg > 9 || (op.cfg >= 6 && op.cfg <= 8))
+                return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..5, 9 (6..8, 10..18 are measurement tiles: `make MEASURE=1`)");
+#endif
             L.cfg = (signed char)op.cfg;
         }
         if (op.kstag >= 0) L.kstag = (signed char)(op.kstag != 0);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 3 (library built with SEQ_DEFS=-DSMK_SEQ_ABLATE): the k-step issue order of wreg_tile, first version vs interleaved,
+"""Round 3 (library built with `make MEASURE=1`): the k-step issue order of wreg_tile, first version vs interleaved,
 inside conv_seq_kernel on the bench's layer shapes (B = 8, one 31x31 image per XCD).  Alternating arms, same process."""
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 3, probe 3 (library built with SEQ_DEFS=-DSMK_SEQ_ABLATE): the K-tile time of a 64x128 sequence tile with parts of the
+"""Round 3, probe 3 (library built with `make MEASURE=1`): the K-tile time of a 64x128 sequence tile with parts of the
 loop removed -- operand refills, MFMAs, A-fragment reads, the K-loop barrier."""
 import os
 import sys
