@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, final code: full GPU suite, the driver's exact bench command (+ per-layer profile), the 200-step line, rocprofv3
 # kernel stats of the driver's command, PMC passes (separate runs, kernel-trace only) and the traffic summary tied to the
-# kernel sources (sha256) that bench.py checks.
+# kernel sources (sha256) that bench.py checks, effective clock per kernel.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/r03final
 O=$R/gpurun_out/r03final
 export SMK_GRAPH=1
@@ -20,7 +20,8 @@ bash tools/measure/gpu_pmc.sh \
   "FETCH_SIZE TCC_HIT_sum SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" \
   "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" 2>&1 | tail -40 > $O/pmc_tail.txt
 cp gpurun_out/pmc/pmc_by_kernel.json $O/pmc_by_kernel.json
-python tools/measure/pmc_traffic.py $O/pmc_by_kernel.json sharp_b8_f16 "profiles/r03f_pmc_by_kernel.json" > $O/pmc_traffic_sharp_b8_f16.json
+python tools/measure/clock_stats.py gpurun_out/pmc/pass2 > $O/kernel_clocks.txt 2>&1     # GRBM_GUI_ACTIVE / dispatch duration (sum over 8 XCDs: MHz / 8)
+python tools/measure/pmc_traffic.py $O/pmc_by_kernel.json sharp_b8_f16 "profiles/r03g_pmc_by_kernel.json" > $O/pmc_traffic_sharp_b8_f16.json
 python - <<PY
 import json
 d=json.loads(open("$O/bench_driver_cmd.json").read().strip().splitlines()[-1])
