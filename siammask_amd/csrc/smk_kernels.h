@@ -152,10 +152,10 @@ struct Tuning {
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
-    int seq = 1;               // fp16, B >= 8: ResNet stages as persistent per-XCD sequences (conv_seq_kernel)
+    int seq = 1;               // fp16: ResNet layer2 .. adjust as ONE persistent per-XCD launch (conv_seq_kernel) for the batches below
     int seq_min_batch = 6, seq_max_batch = 8;      // batches that run layer2 .. adjust as the persistent sequence (engine.cpp seq_wanted)
     int seq_mult_max = 24;                         // ... and the multiples of 8 up to this one
-    int ablate = 0;            // measurement only: conv_wreg_kernel builds without A refills (1) / W refills (2) / MFMA (4)
+    int ablate = 0;            // MEASURE=1 builds only: conv_wreg_kernel with parts of the K loop removed (bits: conv_wreg.hip)
     int seq_tall = 2;          // sequences: 128-row tiles for layers that would otherwise need several 64-row rounds per image
                                // (1: short-K layers only -- the rule with two producer waves; 2: all, measured -1.7 % with four)
     int seq_kstag = 1;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
