@@ -39,6 +39,9 @@ extern "C" {
  *   off (default; measured a net loss at B=8) | auto for long-K few-tile launches | forced factor).
  *   "a_stage" 0|1 (conv_wreg_kernel / conv_seq_kernel producers: activation rows by LDS-DMA with the swizzle on the source
  *   address | global -> VGPR in ascending lane order, swizzle applied by ds_write_b128; same LDS image, bit-identical results).
+ *   "seq_fuse" 0|1|2 (conv_seq_kernel: a Bottleneck's conv3 + the 1x1 convolution that reads it -- the next block's conv1, adjust -- as
+ *   ONE tile routine on 32-row tiles, c3c1_tile.inc: off | every pair the routine has a shape for (default) | layer3's pairs only);
+ *   smk_tune_get("seq_fused_last") = pairs fused in the sequence launched last (read-only diagnostic).
  * Environment: SMK_CHAIN_CLK=1 makes eager (non-graph) runs print the time workgroup 0 spends in each layer of
  * refine_chain_kernel to stderr (measurement aid). */
 int smk_tune(const char *key, int value);
@@ -107,6 +110,8 @@ int smk_op_conv2d(int dtype, int algo, const float *x_dev, int B, int Cin, int H
  *   1 / 0, -1 = the engine's choice.  w_host [Cout,Cin,k,k], b_host [Cout] or NULL; y_dev: device f32 NCHW output or NULL.
  * The launch is repeated `iters` times; *usec_out (optional) = average microseconds of launches 2..iters; clk_us_out
  * (optional, [2*n]) = per layer, the time (team 0, slot 0) spent in its tiles and in the barrier arrival, of the last launch.
+ * Like the engine's own lists, the list goes through the pair fusion (smk_tune "seq_fuse": a Bottleneck's conv3 + the 1x1
+ * convolution that reads it run as one tile routine, c3c1_tile.inc; cfg = -1 on both); *n_fused_out (optional) = pairs fused.
  * Synchronises the stream (test helper). */
 typedef struct smk_seq_op {
     smk_conv_geom g;
@@ -115,7 +120,7 @@ typedef struct smk_seq_op {
     float *y_dev;
 } smk_seq_op;
 int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters, float *usec_out,
-                    float *clk_us_out, void *stream);
+                    float *clk_us_out, int *n_fused_out, void *stream);
 int smk_op_dw_xcorr(int dtype, const float *x_dev, const float *k_dev, int B, int C,
                     int H, int W, int kh, int kw, float *y_dev, void *stream);
 int smk_op_maxpool3x3s2(int dtype, const float *x_dev, int B, int C, int H, int W,

@@ -107,7 +107,7 @@ def lib():
     L.smk_crop_resize.argtypes = [vp, ctypes.c_int64, ci, ci, vp, vp, ci, ci, fp, vp]
     L.smk_paste_mask.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, fp, vp]
     L.smk_paste_labels.argtypes = [fp, ci, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp, vp]
-    L.smk_op_conv_seq.argtypes = [ctypes.POINTER(SeqOp), ci, fp, ci, ctypes.POINTER(ctypes.c_float), fp, vp]
+    L.smk_op_conv_seq.argtypes = [ctypes.POINTER(SeqOp), ci, fp, ci, ctypes.POINTER(ctypes.c_float), fp, ip, vp]
     L.smk_bench_conv.argtypes = [ci, ci, gp, ci, ci, ctypes.POINTER(ctypes.c_float), vp]
     for name in SYMBOLS:
         fn = getattr(L, name)

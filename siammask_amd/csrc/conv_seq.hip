@@ -30,6 +30,7 @@
 namespace smk {
 
 #include "wreg_tile.inc"
+#include "c3c1_tile.inc"
 
 constexpr int SEQ_POLL_TID = 256;              // lane 0 of the first producer wave: it has no loads in flight at the hoist point
 constexpr int SEQ_CLK2_STRIDE = 12;            // u64 per layer of the SMK_SEQ_CLK=2 stamps
@@ -71,13 +72,17 @@ struct TeamWait {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        return *(volatile int *)abort_sh == 0;
+        // (an LDS read: through the generic pointer this was a FLAT load, whose s_waitcnt vmcnt(0) drained the weight fragments
+        //  every consumer wave has in flight here)
+        return *(__attribute__((address_space(3))) volatile int *)abort_sh == 0;
     }
 };
 
 template <int NPW, int CLK = 0>
 __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
+    static_assert(C3C1Lds<256, 1024, 256>::v <= WregLds<4, 3>::v && C3C1Lds<128, 512, 128>::v <= WregLds<4, 3>::v, "LDS of the fused conv3 + conv1 tile");
+    static_assert(NPW == 4, "c3c1_tile computes on all eight waves");
     __shared__ int ctl[4];                               // [0] slot, [1] error flag found at entry, [2] abort
     // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
     // over the XCDs, starting wherever the previous launch stopped, so blockIdx says nothing); slot = arrival ticket
@@ -101,18 +106,21 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         if (threadIdx.x == 0) seq_raise(a, 1);
         return;
     }
-    unsigned nbar = 0, pending = 0;                      // barriers arrived at; target of the one not yet waited for
+    unsigned pending = 0;                                // arrival count of the barrier arrived at and not yet waited for
     const bool clk = a.clk && team == 0 && slot == 0 && threadIdx.x == 0;
     if (clk) a.clk[0] = wall_clock64();
     bool alive = true;
     for (int li = 0; li < a.n && alive; ++li) {
         const SeqLayer &L = a.L[li];
         const int cfg = L.cfg;
+        // cfg 20 / 21: this layer (a Bottleneck's conv3) and the NEXT record (the 1x1 convolution that reads it: cfg 22) run as
+        // ONE tile routine on 32-row tiles, no barrier in between (c3c1_tile.inc; the engine's seq_fuse_pairs marks the pairs)
+        const bool fused = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2;
         const int bn = (cfg == 0 || cfg == 3 || cfg == 16 || cfg == 17) ? 256 : ((cfg == 2 || cfg == 9 || cfg == 18) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
         const int bm = (cfg == 3 || cfg == 4 || cfg == 9 || cfg == 16) ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
         const int hw = L.Ho * L.Wo;
-        const int tiles = ((hw + bm - 1) / bm) * tilesN;
+        const int tiles = fused ? (hw + 31) / 32 : ((hw + bm - 1) / bm) * tilesN;
         const int nk = L.Kpad >> 6;
         // K-loop stagger: the workgroups of a team start at K tiles spread over the whole loop (L.kstag)
         const int kt0 = L.kstag ? (slot * nk) / nslots : 0;
@@ -126,7 +134,12 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                     tclk = (a.clk2 && team == 0 && slot == 0 && img == team && t == slot) ? a.clk2 + SEQ_CLK2_STRIDE * li : nullptr;
                 const TeamWait w{&a, cnt, pending, &ctl[2]};
                 pending = 0;
-                if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
+                if (fused) {
+                    const int fm0 = img * hw + t * 32;
+                    if (cfg == SEQ_CFG_C3C1_L3) alive = c3c1_tile<256, 1024, 256>(L, a.L[li + 1], fm0, m_end, a.B * hw, smem, w);
+                    else alive = c3c1_tile<128, 512, 128>(L, a.L[li + 1], fm0, m_end, a.B * hw, smem, w);
+                }
+                else if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
                 // 128-row tiles: weight fragments ONE K tile ahead (a k-step is 8 MFMAs here, so the cover in time is that of
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
@@ -158,14 +171,18 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
             }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (!alive) break;
-        if (L.sync && li + 1 < a.n) {
+        if (fused) {                                     // the pair's second record: its time is in the first one's span
+            if (clk) a.clk[2 + 2 * li] = a.clk[3 + 2 * li] = wall_clock64();
+            ++li;
+        }
+        if (a.L[li].bar_ord) {                           // (= sync && a layer follows, numbered by launch_conv_seq)
             if (pending) {                               // this workgroup had no tile in the layer: it still has to pass the
                 const TeamWait w{&a, cnt, pending, &ctl[2]};       // previous barrier before it may arrive at the next one
                 pending = 0;
                 if (!w()) break;
             }
             team_arrive(cnt);
-            pending = ++nbar * (unsigned)nslots;
+            pending = (unsigned)a.L[li].bar_ord * (unsigned)nslots;
         }
         if (clk) a.clk[2 + 2 * li] = wall_clock64();
     }
@@ -190,8 +207,20 @@ __global__ void xcc_census_kernel(int *out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (int)(xcc & 0xf);
 }
 
-int launch_conv_seq(const SeqArgs &a, int grid, void *stream) {
-    if (a.n < 1 || a.n > SEQ_MAX || grid < 8 || (grid & 7) || !a.bar || !a.err) return -1;
+int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
+    if (a_in.n < 1 || a_in.n > SEQ_MAX || grid < 8 || (grid & 7) || !a_in.bar || !a_in.err) return -1;
+    SeqArgs a = a_in;
+    unsigned short ord = 0;
+    for (int li = 0; li < a.n; ++li) {
+        const int cfg = a.L[li].cfg;
+        a.L[li].bar_ord = 0;
+        if (cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2) {          // a pair: the second record must follow, its `sync` counts
+            if (li + 1 >= a.n || a.L[li + 1].cfg != SEQ_CFG_C3C1_2ND) return -1;
+            continue;
+        }
+        if (cfg == SEQ_CFG_C3C1_2ND && (li == 0 || (a.L[li - 1].cfg != SEQ_CFG_C3C1_L3 && a.L[li - 1].cfg != SEQ_CFG_C3C1_L2))) return -1;
+        if (a.L[li].sync && li + 1 < a.n) a.L[li].bar_ord = ++ord;
+    }
     if (a.clk2)                                           // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
         hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_seq_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);

@@ -756,6 +756,40 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     return true;
 }
 
+// Pairs (conv3 of a Bottleneck, the 1x1 convolution that reads its output) -> one fused tile routine (c3c1_tile.inc): the 1x1
+// needs every channel of a pixel and no neighbour, so the workgroup that owns 32 whole rows of conv3's output runs it from LDS.
+// Marks the two records of every pair the routine has a shape for; the list itself (tensors, order, barriers behind the pair)
+// stays as recorded.  smk_tune "seq_fuse" 0 leaves the list alone.
+static bool seq_pair_fusable(const SeqLayer &a, const SeqLayer &b, int *code) {
+    auto plain1x1 = [](const SeqLayer &l) {
+        return l.kh == 1 && l.kw == 1 && l.stride == 1 && l.stride_x == 1 && l.pad == 0 && l.org_y == 0 && l.org_x == 0 &&
+               l.Hl == l.Hs && l.Wl == l.Ws && l.Ho == l.Hs && l.Wo == l.Ws && l.Ci == l.Kpad;
+    };
+    if (!plain1x1(a) || !plain1x1(b) || !a.sync) return false;
+    if (!a.res || a.res_mode != RES_PRE_RELU || !a.relu || b.res || b.res_mode != RES_NONE) return false;
+    if (b.in != a.out || b.cin_off != a.cout_off || b.Cs != a.Cos || b.Ci != a.Nst || b.Hs != a.Ho || b.Ws != a.Wo) return false;
+    if (b.out == a.out || b.out == a.res || b.out == a.in) return false;
+    if (a.Kpad == 256 && a.Nst == 1024 && b.Nst == 256) *code = SEQ_CFG_C3C1_L3;
+    else if (a.Kpad == 128 && a.Nst == 512 && b.Nst == 128) *code = SEQ_CFG_C3C1_L2;
+    else return false;
+    return true;
+}
+static int g_seq_fused_last = 0;          // pairs fused in the list that was launched last (smk_tune_get "seq_fused_last", a diagnostic)
+static void seq_fuse_pairs(SeqLayer *L, int n, const std::vector<char> *locked = nullptr) {
+    g_seq_fused_last = 0;
+    if (!g_tune.seq_fuse) return;
+    for (int i = 0; i + 1 < n; ++i) {
+        int code = 0;
+        if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
+        if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L[i], L[i + 1], &code)) continue;
+        if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
+        L[i].cfg = (signed char)code;
+        L[i + 1].cfg = (signed char)SEQ_CFG_C3C1_2ND;
+        ++g_seq_fused_last;
+        ++i;
+    }
+}
+
 // SMK_SEQ_CLK (measurement aid, eager runs only): print what (team 0, slot 0) stamped
 static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids, const char *idn, const unsigned long long *h,
                           const unsigned long long *h2) {
@@ -787,6 +821,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.err = c->seq_err;
         a.err_host = c->seq_err_hdev;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
+        seq_fuse_pairs(a.L, a.n);                        // (a pair never straddles two launches: it is marked inside one list)
         const char *ck = getenv("SMK_SEQ_CLK");
         const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
@@ -1785,6 +1820,7 @@ int smk_tune(const char *key, int value) {
     }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
+    else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_fuse 0|1|2"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
@@ -1823,11 +1859,12 @@ int smk_tune_get(const char *key, int *value) {
         return 0;
     }
     static const struct { const char *name; int *slot; } knobs[] = {
+        {"seq_fused_last", &g_seq_fused_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
@@ -2155,7 +2192,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
 // A sequence of convolutions through conv_seq_kernel on caller-described layers (unit parity of the persistent kernel:
 // every tile configuration, residual and independent-member cases; micro-benchmarks of its K loop).  fp16 only.
 int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters, float *usec_out, float *clk_us_out,
-                    void *stream) {
+                    int *n_fused_out, void *stream) {
     if (!ops || !x_dev || n < 1 || n > SEQ_MAX || iters < 1) return fail(SMK_E_ARG, "smk_op_conv_seq: bad argument (1..%d layers)", SEQ_MAX);
     hipStream_t s = (hipStream_t)stream;
     const int dtype = DT_F16;
@@ -2183,8 +2220,10 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     memset(&a, 0, sizeof(a));
     a.n = n; a.B = B;
     std::vector<std::string> ids;
+    std::vector<char> locked(n, 0);
     for (int i = 0; i < n; ++i) {
         const smk_seq_op &op = ops[i];
+        locked[i] = op.cfg >= 0;
         if (!op.w_host) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d has no weights", i);
         if (op.src >= i || op.res_src >= i) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d reads a later layer", i);
         if (op.g.B != B || op.g.win || op.g.ups) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d: one batch, no windows", i);
@@ -2250,6 +2289,11 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     const bool want2 = ck && !strcmp(ck, "2");
     if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
     a.bar = bar; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
+    seq_fuse_pairs(a.L, a.n, &locked);                   // what the engine does with its own lists (smk_tune "seq_fuse")
+    if (n_fused_out) {
+        *n_fused_out = 0;
+        for (int i = 0; i < n; ++i) *n_fused_out += a.L[i].cfg == SEQ_CFG_C3C1_2ND;
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

@@ -92,7 +92,9 @@ struct SeqLayer {
     int kw_magic;
     // 16-bit fields in 4-byte aligned PAIRS that are read together: the compiler fetches a pair with one scalar load (a pair that
     // straddles a dword boundary becomes a VECTOR load from the kernel-argument segment -- and a vmcnt wait in the producers)
-    unsigned short Hs, Ws, Hl, Wl, Ho, Wo, Cs, cin_off, Ci, Kpad, Nst, Cos, res_Cs, res_coff, cout_off, pad16_;
+    unsigned short Hs, Ws, Hl, Wl, Ho, Wo, Cs, cin_off, Ci, Kpad, Nst, Cos, res_Cs, res_coff, cout_off, bar_ord;
+    // bar_ord: ordinal (1, 2, ...) of the team barrier BEHIND this layer, filled in by launch_conv_seq from `sync` (0 = none) --
+    // the kernel does not carry a barrier count from layer to layer (it sat in a VGPR and was the one value it spilled)
     short org_y, org_x;
     signed char kh, kw, stride, stride_x, pad, dil, relu, res_mode, ci_shift;
     signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128, 9 = 128x64;
@@ -106,6 +108,11 @@ struct SeqLayer {
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
 };
 static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
+// pair codes (engine.cpp seq_fuse_pairs, c3c1_tile.inc): a Bottleneck's conv3 and the 1x1 convolution that reads its output run as
+// ONE tile routine; the first record carries the shape code, the second one is consumed with it
+constexpr int SEQ_CFG_C3C1_L3 = 20;    // K 256 -> N 1024 (+ residual, ReLU) -> N 256   (layer3 conv3 -> next conv1 / adjust)
+constexpr int SEQ_CFG_C3C1_L2 = 21;    // K 128 -> N 512  (+ residual, ReLU) -> N 128   (layer2 conv3 -> next conv1)
+constexpr int SEQ_CFG_C3C1_2ND = 22;   // the pair's second record
 constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
@@ -161,6 +168,8 @@ struct Tuning {
     int seq_kstag = 1;         // sequences: every workgroup of a team starts its K loop at another K tile (0 off, 1 layers whose
                                // weights fit the L2, 2 all)
     int res_nt = 1;            // conv_wreg / conv_seq: residual rows fetched non-temporally (the block input is dead after the add): -0.6 % B=8, -0.8 % B=64, bit-identical
+    int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
+                               // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between
     int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
     int wreg_policy = 1;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer

@@ -75,13 +75,14 @@ SEQ_CFG = {None: -1, (64, 256): 0, (64, 128): 1, (64, 64): 2, (128, 256): 3, (12
            "abl10": 10, "abl11": 11, "abl12": 12, "abl13": 13, "abl14": 14, "old64x128": 15, "old128x256": 16, "old64x256": 17, "old64x64": 18}      # 6..8: measurement builds of the 64x128 tile (wrong results by construction)
 
 
-def conv_seq(x, layers, iters=1, want_outputs=True):
+def conv_seq(x, layers, iters=1, want_outputs=True, info=None):
     """smk_op_conv_seq: a list of convolutions as ONE persistent conv_seq_kernel launch (fp16).
 
     x: [B,C,H,W] float32 CUDA tensor.  layers: dicts with w [Cout,Cin,k,k] (numpy), optional b, stride, pad, dil, relu,
     src (-1 = x, j = output of layer j; default: the previous layer), res (source index of the residual, -1 = x) with
     res_mode 1 (before the ReLU) / 2 (after), sync (default True), tile ((bm, bn), "deep" or None), kstag (-1 engine's choice).
-    Returns (outputs [list of float32 NCHW tensors], usec per launch, per-layer (tiles_us, arrive_us) array)."""
+    Returns (outputs [list of float32 NCHW tensors], usec per launch, per-layer (tiles_us, arrive_us) array); info (a dict,
+    optional) receives "fused_pairs" = the (conv3, next 1x1) pairs the launch ran as one tile routine (smk_tune "seq_fuse")."""
     _chk_cuda(x)
     x = x.contiguous().float()
     B = x.shape[0]
@@ -120,9 +121,12 @@ def conv_seq(x, layers, iters=1, want_outputs=True):
             arr[i].y_dev = None
     us = ctypes.c_float(0.0)
     clk = np.zeros(2 * n, dtype=np.float32)
+    nfused = ctypes.c_int(0)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().smk_op_conv_seq(arr, n, x.data_ptr(), iters, ctypes.byref(us),
-                                              clk.ctypes.data_as(ctypes.c_void_p), _lib.current_stream_ptr()))
+                                              clk.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nfused), _lib.current_stream_ptr()))
+    if info is not None:
+        info["fused_pairs"] = nfused.value
     return outs, us.value, clk.reshape(n, 2)
 
 

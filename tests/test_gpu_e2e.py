@@ -470,10 +470,18 @@ def test_persistent_sequences_and_tail_fusion_are_what_runs_at_b8():
 
     try:
         on, recs, (grid, err) = run(seq=1, chain_mask=1)
+        # ... and inside the sequence the nine (conv3, next 1x1) pairs -- three in layer2, five in layer3, layer3.5's conv3 with
+        # adjust -- run as ONE tile routine each (c3c1_tile.inc): 24 layer records' worth of barriers instead of 33
+        fused = _lib.tune_get("seq_fused_last")
         off, recs_off, _ = run(seq=0, chain_mask=0)
+        unfused, _, (_, err_u) = run(seq=1, chain_mask=1, seq_fuse=0)
+        fused_off = _lib.tune_get("seq_fused_last")
     finally:
-        _lib.tune(seq=1, chain_mask=1)
-    assert grid == 256 and err == 0
+        _lib.tune(seq=1, chain_mask=1, seq_fuse=1)
+    assert grid == 256 and err == 0 and err_u == 0
+    assert fused == 9 and fused_off == 0, (fused, fused_off)
+    for k in ("cls", "loc", "mask", "refine"):
+        assert rel_err(on[k].cpu().numpy(), unfused[k].cpu().numpy()) <= 5e-3, k
     kernels = [r["kernel"].split("<")[0] for r in recs]
     assert kernels.count("conv_seq") == 1 and kernels.count("chain_mask") == 1, kernels
     # the profiler launches the members of merged launches one by one (per-layer attribution), so its count (30) is

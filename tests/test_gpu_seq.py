@@ -128,6 +128,77 @@ def test_conv_seq_real_layer3_block_engine_choice():
     _check(x2, l2, outs, "layer3.0 shortcut")
 
 
+# ---- the fused (conv3, next 1x1) pairs: c3c1_tile.inc ------------------------------------------------------------------------
+def _two_blocks(rng, cin, planes, tail_relu=True):
+    """Bottleneck -> Bottleneck's conv1 (or, with tail_relu False, `adjust`: 1x1 + BN without ReLU, custom.py:19-25): the pair
+    (layer 2, layer 3) is what the engine's lists hold between two identity blocks"""
+    blk = _bottleneck(rng, cin, planes)
+    blk.append(dict(w=_w(rng, planes, cin, 1), b=rng.uniform(-1, 1, planes).astype(np.float32), relu=tail_relu))
+    return blk
+
+
+@pytest.mark.parametrize("shape", [(1024, 256), (512, 128)])
+@pytest.mark.parametrize("B,S", [(3, 23), (8, 31), (10, 15)])
+def test_conv_seq_fused_conv3_conv1_pairs(shape, B, S):
+    """layer3's (256 -> 1024 + residual, ReLU -> 256) and layer2's (128 -> 512 -> 128) pairs as ONE tile routine on 32-row
+    tiles: ragged last tile (23 x 23 = 529 = 16.5 tiles), idle teams (B = 3), the bench's shape (B = 8, 31 x 31: 31 tiles for
+    32 workgroups), two images on two of the teams (B = 10); both outputs of the pair -- conv3's (the next residual) and
+    the 1x1's -- are held to the per-op gate one layer deep, and the unfused list computes the same tensors"""
+    from siammask_amd import _lib
+    ops = _ops()
+    cin, planes = shape
+    rng = np.random.default_rng(71 + cin + B)
+    x = rng.uniform(-1, 1, size=(B, cin, S, S)).astype(np.float32)
+    tail = _bottleneck(rng, planes, planes // 2, dil=1)      # a block behind the pair: its 3x3 reads the 1x1's output across the team barrier
+    tail[2]["res"] = 3
+    layers = _two_blocks(rng, cin, planes) + tail
+    xd = torch.from_numpy(x).cuda()
+    info = {}
+    outs, _, _ = ops.conv_seq(xd, layers, info=info)
+    assert info["fused_pairs"] == 1, info
+    _check(x, layers, outs, "fused pair %s B=%d S=%d" % (shape, B, S))
+    old = _lib.tune_get("seq_fuse")
+    try:
+        _lib.tune(seq_fuse=0)
+        plain, _, _ = ops.conv_seq(xd, layers, info=info)
+    finally:
+        _lib.tune(seq_fuse=old)
+    assert info["fused_pairs"] == 0
+    # conv1 / conv2 / conv3 see the same inputs either way; conv3 differs by summation order only (then fp16 rounding)
+    for i in (0, 1):
+        assert torch.equal(outs[i], plain[i]), i
+    for i in (2, 3):
+        assert rel_err(outs[i].cpu().numpy(), plain[i].cpu().numpy().astype(np.float64)) <= 1e-3, i
+
+
+def test_conv_seq_fused_chain_of_layer3_blocks_and_adjust():
+    """three identity Bottlenecks of layer3 + adjust at the bench's batch: conv1, conv2, [conv3 + conv1], conv2, [conv3 + conv1],
+    conv2, [conv3 + adjust (no ReLU)] -- every fused pair's residual is the previous pair's conv3 output, written from LDS"""
+    ops = _ops()
+    rng = np.random.default_rng(81)
+    x = rng.uniform(-1, 1, size=(8, 1024, 31, 31)).astype(np.float32)
+    layers = []
+    for b in range(3):
+        blk = _bottleneck(rng, 1024, 256)
+        if b:
+            blk[0]["src"] = len(layers) - 1
+            blk[2]["res"] = len(layers) - 1
+        layers += blk
+    layers.append(dict(w=_w(rng, 256, 1024, 1), b=rng.uniform(-1, 1, 256).astype(np.float32), relu=False))
+    for i, l in enumerate(layers):               # absolute residual sources (the helper's default is relative to the block)
+        if "res" in l and l["res"] == -1 and i > 2:
+            raise AssertionError("residual source not set")
+    info = {}
+    xd = torch.from_numpy(x).cuda()
+    outs, us, clk = ops.conv_seq(xd, layers, iters=5, info=info)
+    assert info["fused_pairs"] == 3, info
+    _check(x, layers, outs, "layer3 chain")
+    again, _, _ = ops.conv_seq(xd, layers, info=info)
+    for u, v in zip(outs, again):
+        assert torch.equal(u, v)
+    print("fused layer3 chain: %.1f us per launch; per layer (tiles us): %s" % (us, np.round(clk[:, 0], 1).tolist()))
+
+
 def test_conv_seq_repeated_launches_leave_the_counters_clean():
     """the team counters reset themselves: 20 launches in a row (iters) and a second call give the same bits"""
     ops = _ops()

@@ -177,6 +177,7 @@ def test_tuning_knobs_read_back():
     and the defaults are the measured ones (four producer waves, the layer rule fitted with them, 128-row sequence tiles)."""
     from siammask_amd import _lib
     assert (_lib.tune_get("npw"), _lib.tune_get("wreg_policy"), _lib.tune_get("seq_tall"), _lib.tune_get("a_stage")) == (4, 1, 2, 0)
+    assert _lib.tune_get("seq_fuse") == 1 and _lib.tune_get("seq_fused_last") == 0      # conv3 + next conv1 pairs fused; nothing launched
     old = _lib.tune_get("npw")
     try:
         _lib.tune(npw=2)
