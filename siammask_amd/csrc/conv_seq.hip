@@ -136,8 +136,8 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 pending = 0;
                 if (fused) {
                     const int fm0 = img * hw + t * 32;
-                    if (cfg == SEQ_CFG_C3C1_L3) alive = c3c1_tile<256, 1024, 256>(L, a.L[li + 1], fm0, m_end, a.B * hw, smem, w);
-                    else alive = c3c1_tile<128, 512, 128>(L, a.L[li + 1], fm0, m_end, a.B * hw, smem, w);
+                    if (cfg == SEQ_CFG_C3C1_L3) alive = c3c1_tile<256, 1024, 256, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
+                    else alive = c3c1_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
                 }
                 else if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);

@@ -775,7 +775,7 @@ static bool seq_pair_fusable(const SeqLayer &a, const SeqLayer &b, int *code) {
     return true;
 }
 static int g_seq_fused_last = 0;          // pairs fused in the list that was launched last (smk_tune_get "seq_fused_last", a diagnostic)
-static void seq_fuse_pairs(SeqLayer *L, int n, const std::vector<char> *locked = nullptr) {
+static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *locked = nullptr) {
     g_seq_fused_last = 0;
     if (!g_tune.seq_fuse) return;
     for (int i = 0; i + 1 < n; ++i) {
@@ -783,6 +783,10 @@ static void seq_fuse_pairs(SeqLayer *L, int n, const std::vector<char> *locked =
         if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
         if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L[i], L[i + 1], &code)) continue;
         if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
+        // the routine switches rows beyond the image off with a buffer offset of 0x7ffff000: every tensor must end below it
+        const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
+        const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
+        if (px * widest * 2 >= 0x7fff0000u || L[i].in_bytes >= 0x7fff0000u) continue;
         L[i].cfg = (signed char)code;
         L[i + 1].cfg = (signed char)SEQ_CFG_C3C1_2ND;
         ++g_seq_fused_last;
@@ -802,6 +806,13 @@ static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids,
         const unsigned long long *t = h2 + 12 * i;
         if (!t[0] || !t[6]) continue;
         const double us = (t[6] - t[0]) / 100.0;
+        if (a.L[i].cfg == SEQ_CFG_C3C1_L3 || a.L[i].cfg == SEQ_CFG_C3C1_L2) {       // a fused pair: c3c1_tile's phases
+            fprintf(stderr, "[seq clk2]  %-10s first tile (fused with the next 1x1): team wait %.2f | activation rows -> LDS %.2f | "
+                    "conv3 K loop %.2f | residual -> Y %.2f | Y = relu(..) %.2f | Y stores + second K loop %.2f | its epilogue + stores %.2f us | %.0f MHz\n",
+                    ids[i].c_str(), (t[7] - t[0]) / 100.0, (t[1] - t[7]) / 100.0, (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0,
+                    (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0, us > 0 ? (double)(t[9] - t[8]) / us : 0.0);
+            continue;
+        }
         fprintf(stderr, "[seq clk2]  %-10s first tile: prologue %.2f | team wait %.2f | first operands %.2f | K loop %.2f | other waves %.2f | "
                 "acc -> LDS %.2f | bias/res/stores %.2f | end sync %.2f us | %.0f MHz\n", ids[i].c_str(),
                 t[7] ? (t[7] - t[0]) / 100.0 : 0.0, 0.0, t[7] ? (t[1] - t[7]) / 100.0 : (t[1] - t[0]) / 100.0, (t[2] - t[1]) / 100.0,
@@ -821,7 +832,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.err = c->seq_err;
         a.err_host = c->seq_err_hdev;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
-        seq_fuse_pairs(a.L, a.n);                        // (a pair never straddles two launches: it is marked inside one list)
+        seq_fuse_pairs(a.L, a.n, B);                     // (a pair never straddles two launches: it is marked inside one list)
         const char *ck = getenv("SMK_SEQ_CLK");
         const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
@@ -2289,7 +2300,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     const bool want2 = ck && !strcmp(ck, "2");
     if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
     a.bar = bar; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
-    seq_fuse_pairs(a.L, a.n, &locked);                   // what the engine does with its own lists (smk_tune "seq_fuse")
+    seq_fuse_pairs(a.L, a.n, B, &locked);                   // what the engine does with its own lists (smk_tune "seq_fuse")
     if (n_fused_out) {
         *n_fused_out = 0;
         for (int i = 0; i < n; ++i) *n_fused_out += a.L[i].cfg == SEQ_CFG_C3C1_2ND;
