@@ -749,6 +749,13 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
         }
         if (tiles64 > 64 && p.Nst >= 192 && p.Nst < 512) L.cfg = 3;      // N = 256 on 63x63 images: 128x256, one round (layer1 conv3)
     }
+    // N = 512 with 16 row tiles (layer2.0's 3x3 stride-2 shortcut on a 31x31 output): 32 tiles either as 64x256 or as 128x128 --
+    // the square tile stages 32 KB per K tile instead of 40 KB for the same flops, and these loops run at the CU's 64 B/clk
+    // (smk_tune "seq_ds128", A/B knob)
+    if (g_tune.seq_ds128 && L.cfg == 0 && p.Nst == 512 && (long)p.kh * p.kw * p.Ci >= 1024) {
+        const int hw = p.Ho * p.Wo;
+        if (((hw + 127) / 128) * 4 <= 32) L.cfg = 4;
+    }
     L.sync = 1;
     // K-loop stagger (smk_tune "seq_kstag": 0 off, 1 = layers whose weights fit the XCD's L2 beside the activations, 2 = all)
     L.kstag = (signed char)((g_tune.seq_kstag == 2 || (g_tune.seq_kstag == 1 && (size_t)p.Nst * p.Kpad * 2 <= (3u << 19))) ? 1 : 0);
@@ -760,7 +767,8 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
 // needs every channel of a pixel and no neighbour, so the workgroup that owns 32 whole rows of conv3's output runs it from LDS.
 // Marks the two records of every pair the routine has a shape for; the list itself (tensors, order, barriers behind the pair)
 // stays as recorded.  smk_tune "seq_fuse" 0 leaves the list alone.
-static bool seq_pair_fusable(const SeqLayer &a, const SeqLayer &b, int *code) {
+static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
+    const SeqLayer &a = L[i], &b = L[i + 1];
     auto plain1x1 = [](const SeqLayer &l) {
         return l.kh == 1 && l.kw == 1 && l.stride == 1 && l.stride_x == 1 && l.pad == 0 && l.org_y == 0 && l.org_x == 0 &&
                l.Hl == l.Hs && l.Wl == l.Ws && l.Ho == l.Hs && l.Wo == l.Ws && l.Ci == l.Kpad;
@@ -769,6 +777,16 @@ static bool seq_pair_fusable(const SeqLayer &a, const SeqLayer &b, int *code) {
     if (!a.res || a.res_mode != RES_PRE_RELU || !a.relu || b.res || b.res_mode != RES_NONE) return false;
     if (b.in != a.out || b.cin_off != a.cout_off || b.Cs != a.Cos || b.Ci != a.Nst || b.Hs != a.Ho || b.Ws != a.Wo) return false;
     if (b.out == a.out || b.out == a.res || b.out == a.in) return false;
+    // the routine fetches the residual BEFORE it waits for the team barrier behind layer i - 1: whoever wrote it inside this
+    // list must be separated from layer i by a barrier that the workgroup has already passed, i.e. one behind a layer <= i - 2
+    for (int j = i - 1; j >= 0; --j)
+        if (L[j].out == a.res) {
+            bool passed = false;
+            for (int k = j; k <= i - 2; ++k)          // (the first record of an already marked pair carries no barrier of its own)
+                passed = passed || (L[k].sync && L[k].cfg != SEQ_CFG_C3C1_L3 && L[k].cfg != SEQ_CFG_C3C1_L2);
+            if (!passed) return false;
+            break;
+        }
     if (a.Kpad == 256 && a.Nst == 1024 && b.Nst == 256) *code = SEQ_CFG_C3C1_L3;
     else if (a.Kpad == 128 && a.Nst == 512 && b.Nst == 128) *code = SEQ_CFG_C3C1_L2;
     else return false;
@@ -781,8 +799,11 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
     for (int i = 0; i + 1 < n; ++i) {
         int code = 0;
         if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
-        if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L[i], L[i + 1], &code)) continue;
+        if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L, i, &code)) continue;
         if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
+        // Measured (profiles/r03h_*): -2.6 .. -4.6 % on the B = 8 step; with two images per team (B = 16) a tie or a loss -- every
+        // tile streams both weight packs again, and the tiled layers amortise their fixed cost over two images.  3: fuse at any batch.
+        if (B > 8 && g_tune.seq_fuse != 3) continue;
         // the routine switches rows beyond the image off with a buffer offset of 0x7ffff000: every tensor must end below it
         const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
         const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
@@ -1831,7 +1852,8 @@ int smk_tune(const char *key, int value) {
     }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
-    else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_fuse 0|1|2"); g_tune.seq_fuse = value; }
+    else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
+    else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
@@ -1875,7 +1897,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},

@@ -169,7 +169,9 @@ struct Tuning {
                                // weights fit the L2, 2 all)
     int res_nt = 1;            // conv_wreg / conv_seq: residual rows fetched non-temporally (the block input is dead after the add): -0.6 % B=8, -0.8 % B=64, bit-identical
     int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
-                               // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between
+                               // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = where a team owns one
+                               // image (B <= 8: measured), 2 = layer3's pairs only, 3 = at any batch
+    int seq_ds128 = 0;         // sequences: N = 512 long-K layers whose 64x256 tiling gives exactly one round (layer2.0's shortcut) on 128x128 tiles
     int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only
     int wreg_policy = 1;       // which layers conv_wreg_kernel takes under wreg = 1: 0 = the round-2 table (fitted with two producer
