@@ -31,7 +31,9 @@ namespace smk {
 
 #include "wreg_tile.inc"
 #include "c3c1_tile.inc"
+#include "wreg_halo_tile.inc"
 
+constexpr int HALO_D128 = 6, HALO_D64 = 6;    // weight ring depth (k-steps in flight per consumer wave) of the two patch-sharing tiles
 constexpr int SEQ_POLL_TID = 256;              // lane 0 of the first producer wave: it has no loads in flight at the hoist point
 constexpr int SEQ_CLK2_STRIDE = 12;            // u64 per layer of the SMK_SEQ_CLK=2 stamps
 
@@ -116,11 +118,16 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         // cfg 20 / 21: this layer (a Bottleneck's conv3) and the NEXT record (the 1x1 convolution that reads it: cfg 22) run as
         // ONE tile routine on 32-row tiles, no barrier in between (c3c1_tile.inc; the engine's seq_fuse_pairs marks the pairs)
         const bool fused = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2;
+        // cfg 24 / 25: 3x3 stride-1 convolution on whole-row tiles (128 / 64 pixels x 64 channels) with the activation patch shared
+        // by the nine taps (wreg_halo_tile.inc; the record's wgt_frag is the chunk-major fragment pack)
+        const bool halo = cfg == SEQ_CFG_HALO128 || cfg == SEQ_CFG_HALO64;
         const int bn = (cfg == 0 || cfg == 3 || cfg == 16 || cfg == 17) ? 256 : ((cfg == 2 || cfg == 9 || cfg == 18) ? 64 : 128);     // cfg 1, 4, 5..8: 128 columns
         const int bm = (cfg == 3 || cfg == 4 || cfg == 9 || cfg == 16) ? 128 : 64;
         const int tilesN = (L.Nst + bn - 1) / bn;
         const int hw = L.Ho * L.Wo;
-        const int tiles = fused ? (hw + 31) / 32 : ((hw + bm - 1) / bm) * tilesN;
+        const int halo_rpt = halo ? (cfg == SEQ_CFG_HALO128 ? 128 : 64) / L.Wo : 1;
+        const int halo_tn = (L.Nst + 63) >> 6;
+        const int tiles = fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
         const int nk = L.Kpad >> 6;
         // K-loop stagger: the workgroups of a team start at K tiles spread over the whole loop (L.kstag)
         const int kt0 = L.kstag ? (slot * nk) / nslots : 0;
@@ -138,6 +145,11 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                     const int fm0 = img * hw + t * 32;
                     if (cfg == SEQ_CFG_C3C1_L3) alive = c3c1_tile<256, 1024, 256, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
                     else alive = c3c1_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
+                }
+                else if (halo) {
+                    const int ty = t / halo_tn, hn0 = (t - ty * halo_tn) * 64;
+                    if (cfg == SEQ_CFG_HALO128) alive = wreg_halo_tile<4, NPW, HALO_D128, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
+                    else alive = wreg_halo_tile<2, NPW, HALO_D64, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
                 }
                 else if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);

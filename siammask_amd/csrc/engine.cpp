@@ -95,6 +95,7 @@ struct PackedConv {
     void *w = nullptr;       // device [rows][Kpad] dtype
     void *w_halo = nullptr;  // same weights, K ordered (chunk, kh, kw, c in chunk) for conv3x3_halo_kernel (3x3 only)
     void *w_frag = nullptr;  // same weights in MFMA-fragment order for conv_wreg_kernel (f16 only)
+    void *w_frag_halo = nullptr;  // 3x3, f16: the chunk-major matrix (w_halo's K order) in MFMA-fragment order (wreg_halo_tile, sequences)
     void *w_frag16 = nullptr; // small packs (<= 256 rows, K <= 640: layer1): fragment order of v_mfma_f32_16x16x32_f16 (l1_block_kernel)
     float *bias = nullptr;   // device [rows] f32
     int N = 0;               // real output channels per group
@@ -186,6 +187,21 @@ static int upload_halo_pack(PackedConv &pc, const std::vector<float> &rows_f32, 
                 hp[(size_t)n * pc.Kpad + (size_t)((ci / CH) * 9 + tap) * CH + ci % CH] =
                     rows_f32[(size_t)n * pc.Kpad + (size_t)tap * pc.Ci + ci];
     const size_t cnt = hp.size();
+    if (dtype == DT_F16 && pc.rows % 32 == 0 && pc.Kpad % 16 == 0 && pc.Kpad == 9 * pc.Ci) {
+        // the same matrix in fragment order (upload_frag_pack's layout) for the patch-sharing tile of the sequences
+        const int KS16 = pc.Kpad / 16;
+        std::vector<_Float16> h(cnt);
+        for (int n = 0; n < pc.rows; ++n) {
+            const float *src = hp.data() + (size_t)n * pc.Kpad;
+            const size_t blk = (size_t)(n / 32) * KS16;
+            for (int k = 0; k < pc.Kpad; ++k) {
+                const int lane = (n % 32) + 32 * ((k % 16) / 8);
+                h[((blk + k / 16) * 64 + lane) * 8 + k % 8] = (_Float16)src[k];
+            }
+        }
+        HIPCHK(hipMalloc(&pc.w_frag_halo, cnt * 2));
+        HIPCHK(hipMemcpy(pc.w_frag_halo, h.data(), cnt * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMalloc(&pc.w_halo, cnt * esize(dtype)));
     if (dtype == DT_F16) {
         std::vector<_Float16> h(cnt);
@@ -592,6 +608,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.in = in.p;
     p.wgt = pc.w;
     p.wgt_frag = pc.w_frag;
+    p.wgt_frag_halo = pc.w_frag_halo;
     p.bias = pc.bias;
     p.pos = o.pos;
     p.B = B;
@@ -708,7 +725,16 @@ static int halo_choice(const PackedConv &pc, const ConvParams &p, const ConvOpt 
 // While c->seq_on, run_conv / run_conv_jobs RECORD eligible convolutions instead of launching them; seq_flush turns the
 // recorded list into persistent launches of <= SEQ_MAX layers.  Everything else (non-eligible convolutions, other
 // kernels) flushes first, so program order is preserved.
-static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
+// the patch-sharing tile of the sequences (wreg_halo_tile.inc): can this 3x3 convolution run on whole-row tiles of bm pixels?
+static bool seq_halo_ok(const ConvParams &p, int bm) {
+    if (!p.wgt_frag_halo || p.kh != 3 || p.kw != 3 || p.stride != 1 || p.stride_x != 1 || p.pad != p.dil || p.dil < 1 || p.dil > 4) return false;
+    if (p.Hl != p.Hs || p.Wl != p.Ws || p.org_y || p.org_x || p.Ho != p.Hl || p.Wo != p.Wl) return false;
+    if (p.Ci % 128 || p.Kpad != 9 * p.Ci || p.Wo > bm) return false;       // an even number of 64-channel chunks
+    const int rpt = bm / p.Wo;
+    return (rpt + 2 * p.dil) * (p.Wl + 2 * p.dil) <= 9 * 32;               // patch rows (HALO_NRMAX rounds of 32)
+}
+// force_halo: 0 = the rule below, 128 / 64 = that tile or fail, -1 = never (per-op tests that force another tile)
+static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L, int force_halo = 0) {
     if (!conv_wreg_eligible(p, dtype) || p.groups > 1 || p.pos || p.ups || p.Kpad % 128) return false;
     if (p.kh > 15 || p.kw > 15 || p.stride > 15 || p.pad > 15 || p.dil > 15) return false;
     // the packed record keeps the geometry in 16-bit fields
@@ -755,6 +781,23 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L) {
     if (g_tune.seq_ds128 && L.cfg == 0 && p.Nst == 512 && (long)p.kh * p.kw * p.Ci >= 1024) {
         const int hw = p.Ho * p.Wo;
         if (((hw + 127) / 128) * 4 <= 32) L.cfg = 4;
+    }
+    // 3x3 stride-1 layers with N <= 256 (every Bottleneck's conv2): whole-row tiles x 64 channels with the activation patch shared
+    // by the nine taps -- half the bytes per flop of the 64 x 128 / 64 x 64 im2col tiles (smk_tune "seq_halo").  128 pixels where that
+    // gives the team (nearly) a tile per workgroup (256 channels on 31 x 31: 8 x 4), else 64 (128 channels: 16 x 2).  The long-K
+    // wide-N shortcut of layer3.0 stays on 128 x 256 tiles (same bytes per flop, four times fewer tiles).
+    if (force_halo > 0 || (force_halo == 0 && g_tune.seq_halo && p.Nst <= 256)) {
+        const int tn = (p.Nst + 63) / 64;
+        int bm = force_halo > 0 ? force_halo : 0;
+        if (!bm) {
+            const bool ok128 = seq_halo_ok(p, 128), ok64 = seq_halo_ok(p, 64);
+            const int t128 = ok128 ? ((p.Ho + 128 / p.Wo - 1) / (128 / p.Wo)) * tn : 0;
+            bm = (ok128 && (t128 >= 28 || !ok64)) ? 128 : (ok64 ? 64 : 0);
+        } else if (!seq_halo_ok(p, bm)) return false;
+        if (bm) {
+            L.cfg = (signed char)(bm == 128 ? SEQ_CFG_HALO128 : SEQ_CFG_HALO64);
+            L.wgt_frag = p.wgt_frag_halo;
+        }
     }
     L.sync = 1;
     // K-loop stagger (smk_tune "seq_kstag": 0 off, 1 = layers whose weights fit the XCD's L2 beside the activations, 2 = all)
@@ -1587,7 +1630,7 @@ int smk_destroy(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf) hipFree(kv.second);
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->ks_part) hipFree(c->ks_part);
@@ -1627,7 +1670,7 @@ int smk_finalize_weights(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
     c->conv.clear();
     int rc = build_weights(c);
     if (rc) return rc;
@@ -1709,7 +1752,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
     c->conv.clear();
     c->finalized = false;
     for (int i = 0; i < h.n_conv; ++i) {
@@ -1854,6 +1897,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
+    else if (!strcmp(key, "seq_halo")) g_tune.seq_halo = value != 0;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
@@ -1897,7 +1941,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
@@ -2271,14 +2315,17 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
             if (ops[j].w_host == op.w_host && ops[j].b_host == op.b_host && ops[j].g.Cout == op.g.Cout &&
                 ops[j].g.Cin == op.g.Cin && ops[j].g.k == op.g.k && ops[j].g.cin_len == op.g.cin_len) same = j;
         if (same >= 0) {
-            pc.w = packs[same].w; pc.bias = packs[same].bias; pc.w_frag = packs[same].w_frag;
+            pc.w = packs[same].w; pc.bias = packs[same].bias; pc.w_frag = packs[same].w_frag; pc.w_frag_halo = packs[same].w_frag_halo;
         } else {
             std::vector<float> rows, bias;
             pack_host(&op.g, pc, op.w_host, op.b_host, rows, bias);
             CHK(upload_packed(pc, rows, bias, dtype));
+            if (pc.k == 3) CHK(upload_halo_pack(pc, rows, dtype));       // (+ its fragment-order form: the patch-sharing tile)
             tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
             if (pc.w_frag) tmp.v.push_back(pc.w_frag);
             if (pc.w_frag16) tmp.v.push_back(pc.w_frag16);
+            if (pc.w_halo) tmp.v.push_back(pc.w_halo);
+            if (pc.w_frag_halo) tmp.v.push_back(pc.w_frag_halo);
         }
         packs[i] = pc;
         outs[i].H = Ho; outs[i].W = Wo; outs[i].C = rup(op.g.Cout, 8);
@@ -2295,8 +2342,9 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         ConvParams p;
         CHK(conv_params(&fake, pc, in, &outs[i], B, o, p));
         SeqLayer L;
-        if (!seq_layer_from(p, dtype, L)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence", i);
-        if (op.cfg >= 0) {
+        const int force_halo = op.cfg == SEQ_CFG_HALO128 ? 128 : (op.cfg == SEQ_CFG_HALO64 ? 64 : (op.cfg >= 0 ? -1 : 0));
+        if (!seq_layer_from(p, dtype, L, force_halo)) return fail(SMK_E_ARG, "smk_op_conv_seq: layer %d cannot run inside a sequence%s", i, force_halo > 0 ? " on the patch-sharing tile" : "");
+        if (op.cfg >= 0 && force_halo <= 0) {
 #ifdef SMK_MEASURE
             if (op.cfg > 18) return fail(SMK_E_ARG, "smk_op_conv_seq: cfg 0..18");
 #else
@@ -2631,6 +2679,7 @@ int smk_host_plan_conv(const smk_conv_geom *g, int dtype, int with_res, int *ker
     pc.w = dummy; pc.bias = dummy;
     if (g->k == 3) pc.w_halo = dummy;
     if (dtype == DT_F16) pc.w_frag = dummy;
+    if (dtype == DT_F16 && g->k == 3 && pc.Kpad == 9 * pc.Ci) pc.w_frag_halo = dummy;
     Act out, res;
     out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8); out.p = dummy;
     res = out;

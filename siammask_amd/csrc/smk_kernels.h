@@ -25,6 +25,7 @@ struct ConvParams {
     const void *wgt;       // [Npad][Kpad] (dtype)
     const void *wgt_frag;  // f16 only: the same matrix in MFMA-fragment order (conv_wreg_kernel), or nullptr:
                            //   [Npad/32][Kpad/16][64 lanes][8 halves], lane = (n % 32) + 32 * ((k % 16) / 8)
+    const void *wgt_frag_halo;   // 3x3, f16: fragment order of the CHUNK-MAJOR matrix (K = (chunk of 64 channels, kh, kw, channel)), or nullptr
     const float *bias;     // [Npad] f32 (BN beta' or conv bias; zero padded)
     const void *res;       // optional residual, NHWC [B][Ho][Wo][res_Cs] (dtype)
     void *out;             // NHWC dtype  or  NCHW f32
@@ -113,6 +114,10 @@ static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
 constexpr int SEQ_CFG_C3C1_L3 = 20;    // K 256 -> N 1024 (+ residual, ReLU) -> N 256   (layer3 conv3 -> next conv1 / adjust)
 constexpr int SEQ_CFG_C3C1_L2 = 21;    // K 128 -> N 512  (+ residual, ReLU) -> N 128   (layer2 conv3 -> next conv1)
 constexpr int SEQ_CFG_C3C1_2ND = 22;   // the pair's second record
+// 3x3 stride-1 (dilated) convolutions on whole-row tiles with the activation patch shared by the nine taps (wreg_halo_tile.inc);
+// the record's wgt_frag points at the chunk-major fragment pack (PackedConv::w_frag_halo)
+constexpr int SEQ_CFG_HALO128 = 24;    // 128 pixels (whole output rows) x 64 channels
+constexpr int SEQ_CFG_HALO64 = 25;     // 64 pixels x 64 channels
 constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
@@ -171,6 +176,8 @@ struct Tuning {
     int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
                                // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = where a team owns one
                                // image (B <= 8: measured), 2 = layer3's pairs only, 3 = at any batch
+    int seq_halo = 1;          // sequences: 3x3 stride-1 layers with N <= 256 (the Bottlenecks' conv2) on whole-row tiles with the activation patch
+                               // shared by the nine taps (wreg_halo_tile.inc); 0 = the im2col tiles of wreg_tile
     int seq_ds128 = 0;         // sequences: N = 512 long-K layers whose 64x256 tiling gives exactly one round (layer2.0's shortcut) on 128x128 tiles
     int seq_deep = 0;          // measurement: 64x128 sequence tiles with a 5-deep activation ring, weights four K tiles ahead
     int seq_first_stage = 1;   // first ResNet stage (0..2) inside the sequences; 3 = adjust only

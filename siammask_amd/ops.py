@@ -72,7 +72,8 @@ def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=
 
 SEQ_CFG = {None: -1, (64, 256): 0, (64, 128): 1, (64, 64): 2, (128, 256): 3, (128, 128): 4, "deep": 5,
            "no_a": 6, "no_w": 7, "no_mfma": 8, (128, 64): 9,
-           "abl10": 10, "abl11": 11, "abl12": 12, "abl13": 13, "abl14": 14, "old64x128": 15, "old128x256": 16, "old64x256": 17, "old64x64": 18}      # 6..8: measurement builds of the 64x128 tile (wrong results by construction)
+           "abl10": 10, "abl11": 11, "abl12": 12, "abl13": 13, "abl14": 14, "old64x128": 15, "old128x256": 16, "old64x256": 17, "old64x64": 18,      # 6..8: measurement builds of the 64x128 tile (wrong results by construction)
+           "halo128": 24, "halo64": 25}     # 3x3 stride-1: whole-row tiles (128 / 64 pixels x 64 channels), activation patch shared by the nine taps
 
 
 def conv_seq(x, layers, iters=1, want_outputs=True, info=None):

@@ -128,6 +128,49 @@ def test_conv_seq_real_layer3_block_engine_choice():
     _check(x2, l2, outs, "layer3.0 shortcut")
 
 
+# ---- 3x3 layers on whole-row tiles with the activation patch shared by the nine taps: wreg_halo_tile.inc ------------------------
+@pytest.mark.parametrize("kstag", [0, 1])
+@pytest.mark.parametrize("dil", [1, 2])
+@pytest.mark.parametrize("tile,planes", [("halo128", 256), ("halo128", 128), ("halo64", 128)])
+def test_conv_seq_patch_sharing_tiles(tile, planes, dil, kstag):
+    """a Bottleneck whose conv2 (3x3, dilation 1 / 2, `planes` channels = two or four 64-channel chunks) is forced onto the
+    patch-sharing tile: 23 x 23 images (five whole rows = 115 pixels per 128-pixel tile, the last tile has three; two rows = 46
+    pixels per 64-pixel tile, the last tile has one), B = 3 (idle teams pass every barrier), chunk stagger off / on"""
+    ops = _ops()
+    rng = np.random.default_rng(91 + planes + dil + 10 * kstag + (tile == "halo64"))
+    x = rng.uniform(-1, 1, size=(3, 256, 23, 23)).astype(np.float32)
+    layers = _bottleneck(rng, 256, planes, dil=dil, kstag=kstag)
+    layers[1]["tile"] = tile
+    outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers)
+    _check(x, layers, outs, "%s planes %d dil %d kstag %d" % (tile, planes, dil, kstag))
+
+
+def test_conv_seq_patch_sharing_engine_choice_and_several_images_per_team():
+    """the engine's own rule (smk_tune "seq_halo", default on) on the bench's shapes: layer3's conv2 (256 channels, dilation 2,
+    31 x 31: 8 x 4 tiles of 128 pixels) and layer2's (128 channels, dilation 1: 16 x 2 tiles of 64 pixels) at B = 10 (two
+    images on two of the teams), the 15 x 15 template shape, against the im2col tiles (seq_halo 0): fp16 summation order only"""
+    from siammask_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(95)
+    for (B, S, cin, planes, dil) in ((10, 31, 1024, 256, 2), (8, 31, 512, 128, 1), (8, 15, 1024, 256, 2)):
+        x = rng.uniform(-1, 1, size=(B, cin, S, S)).astype(np.float32)
+        layers = _bottleneck(rng, cin, planes, dil=dil)
+        xd = torch.from_numpy(x).cuda()
+        assert _lib.tune_get("seq_halo") == 1
+        outs, us, clk = ops.conv_seq(xd, layers, iters=3)
+        _check(x, layers, outs, "engine choice B %d S %d planes %d" % (B, S, planes))
+        try:
+            _lib.tune(seq_halo=0)
+            plain, us0, clk0 = ops.conv_seq(xd, layers, iters=3)
+        finally:
+            _lib.tune(seq_halo=1)
+        assert torch.equal(outs[0], plain[0])
+        assert not torch.equal(outs[1], plain[1]) or planes == 0      # another kernel, another summation order
+        for i in (1, 2):
+            assert rel_err(outs[i].cpu().numpy(), plain[i].cpu().numpy().astype(np.float64)) <= 1.5e-3, i
+        print("B %d S %d planes %d: conv2 tiles %.2f us (im2col tiles %.2f us)" % (B, S, planes, clk[1, 0], clk0[1, 0]))
+
+
 # ---- the fused (conv3, next 1x1) pairs: c3c1_tile.inc ------------------------------------------------------------------------
 def _two_blocks(rng, cin, planes, tail_relu=True):
     """Bottleneck -> Bottleneck's conv1 (or, with tail_relu False, `adjust`: 1x1 + BN without ReLU, custom.py:19-25): the pair

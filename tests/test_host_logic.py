@@ -213,12 +213,14 @@ def test_layer_rules_are_the_measured_ones():
     persistent sequence or -1)."""
     # B = 8 (headline): layer2 / layer3 / adjust run inside the sequences -> the sequence tile code is what counts
     assert _plan(8, 1024, 31, 256, 1)[2] == 1                                  # l3.c1   64x128
-    assert _plan(8, 256, 31, 256, 3, pad=2, dil=2)[2] == 1                     # l3.c2   64x128
+    assert _plan(8, 256, 31, 256, 3, pad=2, dil=2)[2] == 24                    # l3.c2   128 pixels (4 whole rows) x 64, patch shared by the taps
+    assert _plan(8, 256, 31, 256, 3, pad=1)[2] == 24                           # l3.0.c2 (dilation 1)
+    assert _plan(8, 256, 15, 256, 3, pad=2, dil=2)[2] == 25                    # ... on the 15x15 template: 64 pixels (4 rows) x 64
     assert _plan(8, 256, 31, 1024, 1, res=True)[2] == 3                        # l3.c3   128x256 (two 64-row rounds otherwise)
     assert _plan(8, 512, 31, 1024, 3, pad=1)[2] == 3                           # l3.0.ds 128x256 (long K too, seq_tall = 2)
     assert _plan(8, 256, 63, 512, 3, stride=2)[2] == 0                         # l2.0.ds 64x256 (one round)
     assert _plan(8, 256, 63, 128, 1)[2] == 4                                   # l2.0.c1 on the 63x63 input: 128x128
-    assert _plan(8, 128, 31, 128, 3, pad=1)[2] == 2                            # l2.c2   64x64
+    assert _plan(8, 128, 31, 128, 3, pad=1)[2] == 25                           # l2.c2   64 pixels (2 whole rows) x 64, patch shared
     assert _plan(8, 128, 31, 512, 1, res=True)[2] == 0                         # l2.c3   64x256
     # B = 8 per launch
     assert _plan(8, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))               # conv_search (N-fused 768)
