@@ -496,6 +496,12 @@ def main():
         # (uneven XCD placement, barrier timeout) means the timed results are not trustworthy -> no line
         g_, e_ = w.model.seq_status()
         seq = {"workgroups": g_, "err": e_}
+        try:    # what the sequence launched last was made of (diagnostics of the library's layer rules)
+            from siammask_amd import _lib
+            seq["fused_conv3_conv1_pairs"] = _lib.tune_get("seq_fused_last")
+            seq["patch_sharing_3x3_tiles"] = bool(_lib.tune_get("seq_halo"))
+        except Exception:
+            pass
     roof, recs = None, []
     if not args.stub:
         try:

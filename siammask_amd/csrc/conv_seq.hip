@@ -33,7 +33,15 @@ namespace smk {
 #include "c3c1_tile.inc"
 #include "wreg_halo_tile.inc"
 
-constexpr int HALO_D128 = 6, HALO_D64 = 6;    // weight ring depth (k-steps in flight per consumer wave) of the two patch-sharing tiles
+// weight ring depth (k-steps in flight per consumer wave) of the two patch-sharing tiles, and one (SB = 1) or two sets of activation
+// fragments (measured: tools/measure/gpu_halo_probe.sh builds the other combinations with -DSMK_HALO_D128=.. -DSMK_HALO_SB128=..)
+#ifndef SMK_HALO_D128
+#define SMK_HALO_D128 3      // (3 = 6 in time, profiles/r03h_halo_first_contact.txt: the loop is not latency-bound; 6 costs 24 registers and spills)
+#endif
+#ifndef SMK_HALO_SB128
+#define SMK_HALO_SB128 0
+#endif
+constexpr int HALO_D128 = SMK_HALO_D128, HALO_SB128 = SMK_HALO_SB128, HALO_D64 = 6;
 constexpr int SEQ_POLL_TID = 256;              // lane 0 of the first producer wave: it has no loads in flight at the hoist point
 constexpr int SEQ_CLK2_STRIDE = 12;            // u64 per layer of the SMK_SEQ_CLK=2 stamps
 
@@ -148,8 +156,8 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 }
                 else if (halo) {
                     const int ty = t / halo_tn, hn0 = (t - ty * halo_tn) * 64;
-                    if (cfg == SEQ_CFG_HALO128) alive = wreg_halo_tile<4, NPW, HALO_D128, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
-                    else alive = wreg_halo_tile<2, NPW, HALO_D64, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
+                    if (cfg == SEQ_CFG_HALO128) alive = wreg_halo_tile<4, NPW, HALO_D128, HALO_SB128, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
+                    else alive = wreg_halo_tile<2, NPW, HALO_D64, 0, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
                 }
                 else if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);

@@ -731,7 +731,7 @@ static bool seq_halo_ok(const ConvParams &p, int bm) {
     if (p.Hl != p.Hs || p.Wl != p.Ws || p.org_y || p.org_x || p.Ho != p.Hl || p.Wo != p.Wl) return false;
     if (p.Ci % 128 || p.Kpad != 9 * p.Ci || p.Wo > bm) return false;       // an even number of 64-channel chunks
     const int rpt = bm / p.Wo;
-    return (rpt + 2 * p.dil) * (p.Wl + 2 * p.dil) <= 9 * 32;               // patch rows (HALO_NRMAX rounds of 32)
+    return (rpt + 2 * p.dil) * (p.Wl + 2 * p.dil) * 9 <= 10 * 256;         // patch pieces (HALO_NRMAX rounds of 256; 144-byte rows)
 }
 // force_halo: 0 = the rule below, 128 / 64 = that tile or fail, -1 = never (per-op tests that force another tile)
 static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L, int force_halo = 0) {
