@@ -844,9 +844,9 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
         if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
         if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L, i, &code)) continue;
         if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
-        // Measured (profiles/r03h_*): -2.6 .. -4.6 % on the B = 8 step; with two images per team (B = 16) a tie or a loss -- every
-        // tile streams both weight packs again, and the tiled layers amortise their fixed cost over two images.  3: fuse at any batch.
-        if (B > 8 && g_tune.seq_fuse != 3) continue;
+        // Measured (profiles/r03h_*): -4.3 .. -5.5 % on the B = 8 step, -2.0 % at B = 16 and -2.7 % at B = 24 (two / three images per
+        // team: every tile streams both weight packs again, but with the residual fetched in front of the team wait it still pays;
+        // the first version, which fetched it behind, was +0.6 % at B = 16 and was limited to B <= 8)
         // the routine switches rows beyond the image off with a buffer offset of 0x7ffff000: every tensor must end below it
         const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
         const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
@@ -985,7 +985,10 @@ static bool seq_wanted(const smk_ctx *c, int B) {
     // XCDs: the per-launch kernels spread an image over the chip), B = 5 and 12 x1.00, B = 10 x0.97 (two XCDs run two images),
     // B = 32 x0.95 (four images in sequence on 64-row tiles lose to the chip-wide 128 / 256-row tiles).
     if (!g_tune.seq || c->seq_grid <= 0 || c->dtype != DT_F16) return false;
+    // End of round 3 (fused pairs, patch-sharing tiles: the sequence itself 13 % faster; profiles/r03h_seq_batch_sweep.txt): B = 5 x1.076 and
+    // B = 12 x1.029 join; B = 3 / 4 x0.954 / 0.983, B = 10 x0.990, B = 32 x0.955 stay on the per-launch path.
     if (B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch) return true;
+    if (B == g_tune.seq_extra_batch) return true;
     return B % 8 == 0 && B <= g_tune.seq_mult_max;
 }
 
@@ -1903,6 +1906,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
+    else if (!strcmp(key, "seq_extra_batch")) g_tune.seq_extra_batch = value;
     else if (!strcmp(key, "seq_mult_max")) { if (value < 0) return fail(SMK_E_ARG, "seq_mult_max >= 0"); g_tune.seq_mult_max = value; }
     else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
@@ -1943,7 +1947,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
-        {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
+        {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
         {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
