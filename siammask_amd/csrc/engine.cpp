@@ -803,6 +803,11 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L, int forc
     // K-loop stagger (smk_tune "seq_kstag": 0 off, 1 = layers whose weights fit the XCD's L2 beside the activations, 2 = all)
     L.kstag = (signed char)((g_tune.seq_kstag == 2 || (g_tune.seq_kstag == 1 && (size_t)p.Nst * p.Kpad * 2 <= (3u << 19))) ? 1 : 0);
     if (g_tune.seq_deep && L.cfg == 1) L.cfg = 5;         // measurement variant (smk_tune "seq_deep")
+    {   // (smk_tune "seq_kstag_mask": which tile routines stagger -- 1 fused pairs, 2 patch-sharing tiles, 4 the im2col tiles)
+        const bool is_halo = L.cfg == SEQ_CFG_HALO128 || L.cfg == SEQ_CFG_HALO64;
+        if (is_halo && !(g_tune.seq_kstag_mask & 2)) L.kstag = 0;
+        if (!is_halo && !(g_tune.seq_kstag_mask & 4)) L.kstag = 0;
+    }
     return true;
 }
 
@@ -844,15 +849,18 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
         if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
         if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L, i, &code)) continue;
         if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
-        // Measured (profiles/r03h_*): -4.3 .. -5.5 % on the B = 8 step, -2.0 % at B = 16 and -2.7 % at B = 24 (two / three images per
-        // team: every tile streams both weight packs again, but with the residual fetched in front of the team wait it still pays;
-        // the first version, which fetched it behind, was +0.6 % at B = 16 and was limited to B <= 8)
+        // Measured (profiles/r03h_*): -4.3 .. -5.5 % on the B = 8 step; -2.0 % at B = 16 and -2.7 % at B = 24 too -- but with TWO images
+        // per team, layer2's pairs fused, the patch-sharing tiles AND a K-loop stagger anywhere, B = 12 gave a wrong p2 for the first image
+        // of a two-image team on two of three boxes (profiles/r03h_b12_race.txt: timing dependent, root cause not found).  Until it is,
+        // the fusion runs only where a team owns ONE image, the configuration every gate of the suite holds; 3 forces it (per-op tests).
+        if (B > 8 && g_tune.seq_fuse != 3) continue;
         // the routine switches rows beyond the image off with a buffer offset of 0x7ffff000: every tensor must end below it
         const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
         const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
         if (px * widest * 2 >= 0x7fff0000u || L[i].in_bytes >= 0x7fff0000u) continue;
         L[i].cfg = (signed char)code;
         L[i + 1].cfg = (signed char)SEQ_CFG_C3C1_2ND;
+        if (!(g_tune.seq_kstag_mask & 1)) L[i].kstag = 0;
         ++g_seq_fused_last;
         ++i;
     }
@@ -985,8 +993,9 @@ static bool seq_wanted(const smk_ctx *c, int B) {
     // XCDs: the per-launch kernels spread an image over the chip), B = 5 and 12 x1.00, B = 10 x0.97 (two XCDs run two images),
     // B = 32 x0.95 (four images in sequence on 64-row tiles lose to the chip-wide 128 / 256-row tiles).
     if (!g_tune.seq || c->seq_grid <= 0 || c->dtype != DT_F16) return false;
-    // End of round 3 (fused pairs, patch-sharing tiles: the sequence itself 13 % faster; profiles/r03h_seq_batch_sweep.txt): B = 5 x1.076 and
-    // B = 12 x1.029 join; B = 3 / 4 x0.954 / 0.983, B = 10 x0.990, B = 32 x0.955 stay on the per-launch path.
+    // End of round 3 (fused pairs, patch-sharing tiles: the sequence itself 13 % faster; profiles/r03h_seq_batch_sweep.txt): B = 5 x1.076
+    // joins; B = 12 x1.029 would (seq_extra_batch) but stays off with the open item of seq_fuse_pairs; B = 3 / 4 x0.954 / 0.983, B = 10 x0.990,
+    // B = 32 x0.955 stay on the per-launch path.
     if (B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch) return true;
     if (B == g_tune.seq_extra_batch) return true;
     return B % 8 == 0 && B <= g_tune.seq_mult_max;
@@ -1901,6 +1910,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
     else if (!strcmp(key, "seq_halo")) g_tune.seq_halo = value != 0;
+    else if (!strcmp(key, "seq_kstag_mask")) g_tune.seq_kstag_mask = value & 7;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
     else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
@@ -1945,7 +1955,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
