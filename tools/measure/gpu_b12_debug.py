@@ -37,21 +37,24 @@ def run(**knobs):
 
 
 base, _ = run(seq=0)
-for knobs in (dict(seq=1, seq_kstag_mask=7), dict(seq=1, seq_kstag_mask=7), dict(seq=1, seq_kstag_mask=7, seq_fuse=2)):
+for knobs in (dict(seq=1, seq_extra_batch=B, seq_fuse=3), dict(seq=1, seq_extra_batch=B, seq_fuse=3), dict(seq=1, seq_extra_batch=B, seq_fuse=3)):
     d, st = run(**knobs)
     print("== %s  status %s  fused pairs (last launch) %d" % (knobs, st, _lib.tune_get("seq_fused_last")))
     for n in ("p2", "p3"):
         per = [float(np.abs(d[n][b] - base[n][b]).max() / (np.abs(base[n][b]).max() + 1e-30)) for b in range(B)]
         print("   %-7s per image: %s" % (n, " ".join("%.1e" % v for v in per)))
         for b in range(B):
-            if per[b] > 1e-2:
+            if per[b] > 1e-2 and n == "p2":
                 e = np.abs(d[n][b] - base[n][b]) / (np.abs(base[n][b]).max() + 1e-30)      # [C, H, W]
                 C = e.shape[0]
                 px = e.reshape(C, -1)
                 bad_px = np.nonzero(px.max(axis=0) > 1e-2)[0]
                 bad_ch = np.nonzero(px.max(axis=1) > 1e-2)[0]
-                print("      image %d %s: %d bad pixels (first %s ... last %s), by 32-pixel block: %s" % (
-                    b, n, len(bad_px), bad_px[:6].tolist(), bad_px[-3:].tolist(), sorted(set((bad_px // 32).tolist()))))
-                print("      bad channels: %d of %d, by 64-channel block: %s; first %s" % (
-                    len(bad_ch), C, sorted(set((bad_ch // 64).tolist())), bad_ch[:8].tolist()))
-_lib.tune(seq=1, seq_kstag_mask=7, seq_fuse=1)
+                print("      image %d %s: %d bad pixels of %d: 32-pixel blocks %s; image rows %s" % (
+                    b, n, len(bad_px), px.shape[1], sorted(set((bad_px // 32).tolist())), sorted(set((bad_px // 31).tolist()))))
+                print("      first bad pixels %s" % bad_px[:24].tolist())
+                print("      bad channels: %d of %d; 64-channel blocks %s; first %s" % (
+                    len(bad_ch), C, sorted(set((bad_ch // 64).tolist())), bad_ch[:12].tolist()))
+                worst = np.unravel_index(np.argmax(e), e.shape)
+                print("      worst at (c, y, x) = %s: got %.4f want %.4f" % (worst, d[n][b][worst], base[n][b][worst]))
+_lib.tune(seq=1, seq_extra_batch=0, seq_fuse=1)
