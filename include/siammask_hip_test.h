@@ -40,8 +40,8 @@ extern "C" {
  *   "a_stage" 0|1 (conv_wreg_kernel / conv_seq_kernel producers: activation rows by LDS-DMA with the swizzle on the source
  *   address | global -> VGPR in ascending lane order, swizzle applied by ds_write_b128; same LDS image, bit-identical results).
  *   "seq_fuse" 0..3 (conv_seq_kernel: a Bottleneck's conv3 + the 1x1 convolution that reads it -- the next block's conv1, adjust -- as
- *   ONE tile routine on 32-row tiles, c3c1_tile.inc: off | every pair the routine has a shape for where a team owns one image, B <= 8
- *   (default) | layer3's pairs only | at any batch);   "seq_ds128" 0|1 (layer2.0's 3x3 stride-2 shortcut on 128x128 sequence tiles)
+ *   ONE tile routine on 32-row tiles, c3c1_tile.inc: off | every pair the routine has a shape for (default) | layer3's pairs only |
+ *   same as 1);   "seq_ds128" 0|1 (layer2.0's 3x3 stride-2 shortcut on 128x128 sequence tiles)
  *   smk_tune_get("seq_fused_last") = pairs fused in the sequence launched last (read-only diagnostic).
  * Environment: SMK_CHAIN_CLK=1 makes eager (non-graph) runs print the time workgroup 0 spends in each layer of
  * refine_chain_kernel to stderr (measurement aid). */

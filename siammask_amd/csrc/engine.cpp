@@ -527,6 +527,20 @@ static int build_arena(smk_ctx *c) {
     CHK(alloc_buf(c, "a", 63 * 63 * 256));
     CHK(alloc_buf(c, "b", 63 * 63 * 256));
     CHK(alloc_buf(c, "p1", 63 * 63 * 256));
+    // layer2 / layer3 have their OWN intermediates, one layout per buffer (run_backbone): inside the persistent sequence the eight
+    // teams are not synchronised with each other, and a buffer that changes its image pitch between layers lets a team that is ahead
+    // write over the images of a team that is behind (found at B = 9..14: profiles/r03h_b12_race.txt)
+    CHK(alloc_buf(c, "t1_s", 63 * 63 * 128));        // layer2.0 conv1 output (in front of the stride-2 conv2)
+    CHK(alloc_buf(c, "t1_2", 31 * 31 * 128));
+    CHK(alloc_buf(c, "t2_2", 31 * 31 * 128));
+    CHK(alloc_buf(c, "r_2", 31 * 31 * 512));
+    CHK(alloc_buf(c, "a_2", 31 * 31 * 512));
+    CHK(alloc_buf(c, "b_2", 31 * 31 * 512));
+    CHK(alloc_buf(c, "t1_3", 31 * 31 * 256));
+    CHK(alloc_buf(c, "t2_3", 31 * 31 * 256));
+    CHK(alloc_buf(c, "r_3", 31 * 31 * 1024));
+    CHK(alloc_buf(c, "a_3", 31 * 31 * 1024));
+    CHK(alloc_buf(c, "b_3", 31 * 31 * 1024));
     CHK(alloc_buf(c, "p2", 31 * 31 * 512));
     CHK(alloc_buf(c, "search", 31 * 31 * 256));
     CHK(alloc_buf(c, "zf", 7 * 7 * 256));
@@ -849,11 +863,8 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
         if (locked && ((*locked)[i] || (*locked)[i + 1])) continue;        // (per-op tests: the caller forced a tile)
         if (L[i].cfg >= SEQ_CFG_C3C1_L3 || L[i + 1].cfg >= SEQ_CFG_C3C1_L3 || !seq_pair_fusable(L, i, &code)) continue;
         if (g_tune.seq_fuse == 2 && code != SEQ_CFG_C3C1_L3) continue;      // (2: layer3's pairs only, A/B knob)
-        // Measured (profiles/r03h_*): -4.3 .. -5.5 % on the B = 8 step; -2.0 % at B = 16 and -2.7 % at B = 24 too -- but with TWO images
-        // per team, layer2's pairs fused, the patch-sharing tiles AND a K-loop stagger anywhere, B = 12 gave a wrong p2 for the first image
-        // of a two-image team on two of three boxes (profiles/r03h_b12_race.txt: timing dependent, root cause not found).  Until it is,
-        // the fusion runs only where a team owns ONE image, the configuration every gate of the suite holds; 3 forces it (per-op tests).
-        if (B > 8 && g_tune.seq_fuse != 3) continue;
+        // Measured (profiles/r03h_*): -4.3 .. -5.5 % on the B = 8 step, -2.0 % at B = 16, -2.7 % at B = 24.  (What looked like a race of
+        // this routine at B = 12 was a buffer shared by two layouts inside the launch, see build_arena; profiles/r03h_b12_race.txt.)
         // the routine switches rows beyond the image off with a buffer offset of 0x7ffff000: every tensor must end below it
         const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
         const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
@@ -993,9 +1004,8 @@ static bool seq_wanted(const smk_ctx *c, int B) {
     // XCDs: the per-launch kernels spread an image over the chip), B = 5 and 12 x1.00, B = 10 x0.97 (two XCDs run two images),
     // B = 32 x0.95 (four images in sequence on 64-row tiles lose to the chip-wide 128 / 256-row tiles).
     if (!g_tune.seq || c->seq_grid <= 0 || c->dtype != DT_F16) return false;
-    // End of round 3 (fused pairs, patch-sharing tiles: the sequence itself 13 % faster; profiles/r03h_seq_batch_sweep.txt): B = 5 x1.076
-    // joins; B = 12 x1.029 would (seq_extra_batch) but stays off with the open item of seq_fuse_pairs; B = 3 / 4 x0.954 / 0.983, B = 10 x0.990,
-    // B = 32 x0.955 stay on the per-launch path.
+    // End of round 3 (fused pairs, patch-sharing tiles: the sequence itself 13 % faster; profiles/r03h_seq_batch_sweep.txt): B = 5 x1.076 and
+    // B = 12 x1.029 (seq_extra_batch) join; B = 3 / 4 x0.954 / 0.983, B = 10 x0.990, B = 32 x0.955 stay on the per-launch path.
     if (B >= g_tune.seq_min_batch && B <= g_tune.seq_max_batch) return true;
     if (B == g_tune.seq_extra_batch) return true;
     return B % 8 == 0 && B <= g_tune.seq_mult_max;
@@ -1255,8 +1265,11 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
                 cur = out1;
                 continue;
             }
-            Act t1 = act(c, "t1", sp, sp, planes);
-            Act t2 = act(c, "t2", so, so, planes);
+            // one layout per buffer (see build_arena): stage-private names, and layer2.0's pre-stride conv1 output on its own
+            static const char *T1N[3] = {"t1", "t1_2", "t1_3"}, *T2N[3] = {"t2", "t2_2", "t2_3"}, *RN[3] = {"r", "r_2", "r_3"},
+                              *AN[3] = {"a", "a_2", "a_3"}, *BN[3] = {"b", "b_2", "b_3"};
+            Act t1 = act(c, stride == 2 ? "t1_s" : T1N[st], sp, sp, planes);
+            Act t2 = act(c, T2N[st], so, so, planes);
             ConvOpt o1; o1.relu = 1;
             ConvOpt o2; o2.relu = 1; o2.stride = stride; o2.pad = pad2; o2.dil = dil;
             Act res = cur;
@@ -1264,7 +1277,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             const std::string id_ds = id + "ds", id_c1 = id + "c1";
             if (b == 0) {
                 // the shortcut conv only depends on the block input: it shares a launch with conv1
-                Act r = act(c, "r", so, so, planes * 4);
+                Act r = act(c, RN[st], so, so, planes * 4);
                 ConvOpt od;
                 if (st == 0) { od.stride = 1; od.pad = 0; }          // 1x1
                 else if (st == 1) { od.stride = 2; od.pad = 0; }     // 3x3 s2 p0
@@ -1284,8 +1297,8 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
             if (b == 0 && par) CHK(stream_dep(c, c->side[0], s));
             const bool last = b == STAGE_BLOCKS[st] - 1;
-            const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : "a") : ((b & 1) ? "b" : "a");
-            if (last && st == 2 && cur.p == c->buf.at("a")) oname = "b";
+            const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : AN[2]) : ((b & 1) ? BN[st] : AN[st]);
+            if (last && st == 2 && cur.p == c->buf.at(AN[2])) oname = BN[2];
             Act out = act(c, oname, so, so, planes * 4);
             if (last && st == 2) c->p3_buf = oname;
             ConvOpt o3; o3.relu = 1; o3.res = &res; o3.res_mode = RES_PRE_RELU;

@@ -166,7 +166,7 @@ struct Tuning {
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
     int seq = 1;               // fp16: ResNet layer2 .. adjust as ONE persistent per-XCD launch (conv_seq_kernel) for the batches below
     int seq_min_batch = 5, seq_max_batch = 8;      // batches that run layer2 .. adjust as the persistent sequence (engine.cpp seq_wanted)
-    int seq_extra_batch = 0;                       // ... one more batch (12 measured x1.029: four XCDs with two images, four with one; off, see seq_fuse_pairs)
+    int seq_extra_batch = 12;                      // ... one more measured batch (four XCDs with two images, four with one: x1.029)
     int seq_mult_max = 24;                         // ... and the multiples of 8 up to this one
     int ablate = 0;            // MEASURE=1 builds only: conv_wreg_kernel with parts of the K loop removed (bits: conv_wreg.hip)
     int seq_tall = 2;          // sequences: 128-row tiles for layers that would otherwise need several 64-row rounds per image
@@ -175,8 +175,8 @@ struct Tuning {
                                // weights fit the L2, 2 all)
     int res_nt = 1;            // conv_wreg / conv_seq: residual rows fetched non-temporally (the block input is dead after the add): -0.6 % B=8, -0.8 % B=64, bit-identical
     int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
-                               // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = where a team owns one
-                               // image (B <= 8), 2 = layer3's pairs only (A/B knob), 3 = at any batch (per-op tests; see seq_fuse_pairs)
+                               // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = every pair the routine has a
+                               // shape for, 2 = layer3's pairs only (A/B knob), 3 = same as 1
     int seq_halo = 1;          // sequences: 3x3 stride-1 layers with N <= 256 (the Bottlenecks' conv2) on whole-row tiles with the activation patch
                                // shared by the nine taps (wreg_halo_tile.inc); 0 = the im2col tiles of wreg_tile
     int seq_kstag_mask = 7;    // which tile routines of the sequences stagger their K loops: 1 = fused pairs, 2 = patch-sharing tiles, 4 = im2col tiles

@@ -492,9 +492,9 @@ def test_persistent_sequences_and_tail_fusion_are_what_runs_at_b8():
         assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, k
 
 
-@pytest.mark.parametrize("B,expect_seq", [(4, False), (5, True), (7, True), (10, False), (12, False), (16, True), (24, True), (32, False)])
+@pytest.mark.parametrize("B,expect_seq", [(4, False), (5, True), (7, True), (10, False), (12, True), (16, True), (24, True), (32, False)])
 def test_which_batches_run_the_persistent_sequence(B, expect_seq):
-    """engine.cpp seq_wanted (profiles/r03_seq_batch_sweep.txt, r03h_seq_batch_sweep.txt): the sequence runs where it was measured faster -- B = 5..8, 16, 24 --
+    """engine.cpp seq_wanted (profiles/r03_seq_batch_sweep.txt, r03h_seq_batch_sweep.txt): the sequence runs where it was measured faster -- B = 5..8, 12, 16, 24 (12: uneven teams, four XCDs with two images) --
     and nowhere else; where it runs, several images per XCD in turn (B = 16, 24) or idle XCDs (B = 6, 7) give the per-launch path's outputs
     up to fp16 summation order, and the device error flag stays 0."""
     from siammask_amd import _lib
@@ -525,6 +525,37 @@ def test_which_batches_run_the_persistent_sequence(B, expect_seq):
                 assert rel_err(on[k].cpu().numpy(), off[k].cpu().numpy()) <= 5e-3, (B, k)
     finally:
         _lib.tune(seq=1)
+
+
+@pytest.mark.parametrize("B", [9, 10, 13])
+def test_uneven_teams_do_not_write_over_each_other(B):
+    """the persistent sequence forced on for batches where some teams own two images and some one (the teams are not synchronised
+    with each other; the one-image teams run a stage ahead): every intermediate of layer2 / layer3 has its own buffer with ONE
+    layout, so p2 / p3 / search agree with the per-launch path for every image.  (With layer2.0's 63x63 conv1 output and the 31x31
+    conv1 outputs in one buffer, images 0 / 1 of the slow teams were overwritten: profiles/r03h_b12_race.txt.)"""
+    from siammask_amd import _lib
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=11)).cuda()
+    x = torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=11)).cuda()
+    twh = torch.tensor([[60.0, 80.0]] * B, dtype=torch.float64).cuda()
+
+    def run(**knobs):
+        _lib.tune(**knobs)
+        m = _model("sharp", "synthetic_damped", "f16", True, max_batch=B)
+        m.template(z)
+        m.track_step(x, twh, refine=True)
+        out = {n: m.debug_tensor(n).cpu().numpy().astype(np.float64) for n in ("p2", "p3", "search")}
+        st = m.seq_status()
+        return out, st
+
+    try:
+        off, _ = run(seq=0)
+        on, (grid, err) = run(seq=1, seq_min_batch=1, seq_max_batch=64)
+    finally:
+        _lib.tune(seq=1, seq_min_batch=5, seq_max_batch=8)
+    assert grid == 256 and err == 0
+    for n in on:
+        per = [rel_err(on[n][b], off[n][b]) for b in range(B)]
+        assert max(per) <= 5e-3, (B, n, ["%.0e" % v for v in per])
 
 
 @pytest.mark.parametrize("B", [8, 16])

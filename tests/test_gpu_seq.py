@@ -185,7 +185,7 @@ def _two_blocks(rng, cin, planes, tail_relu=True):
 def test_conv_seq_fused_conv3_conv1_pairs(shape, B, S):
     """layer3's (256 -> 1024 + residual, ReLU -> 256) and layer2's (128 -> 512 -> 128) pairs as ONE tile routine on 32-row
     tiles: ragged last tile (23 x 23 = 529 = 16.5 tiles), idle teams (B = 3), the bench's shape (B = 8, 31 x 31: 31 tiles for
-    32 workgroups), two images on two of the teams (B = 10, forced: seq_fuse 3); both outputs of the pair -- conv3's (the next residual) and
+    32 workgroups), two images on two of the teams (B = 10); both outputs of the pair -- conv3's (the next residual) and
     the 1x1's -- are held to the per-op gate one layer deep, and the unfused list computes the same tensors"""
     from siammask_amd import _lib
     ops = _ops()
@@ -200,10 +200,6 @@ def test_conv_seq_fused_conv3_conv1_pairs(shape, B, S):
     old = _lib.tune_get("seq_fuse")
     assert old == 1
     try:
-        if B > 8:                                 # the default fuses only where a team owns ONE image (engine.cpp seq_fuse_pairs)
-            ops.conv_seq(xd, layers, info=info, want_outputs=False)
-            assert info["fused_pairs"] == 0, info
-            _lib.tune(seq_fuse=3)
         outs, _, _ = ops.conv_seq(xd, layers, info=info)
         assert info["fused_pairs"] == 1, info
         _lib.tune(seq_fuse=0)
