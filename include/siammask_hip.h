@@ -139,13 +139,21 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
 /* persistent per-XCD convolution sequences (fp16, batch 8: ResNet layer2 / layer3 / adjust run as ONE conv_seq_kernel launch,
  * one workgroup per CU, image b on XCD b % 8).  The kernel needs every workgroup resident at once; when that fails (a
  * neighbour that holds CUs for more than 0.2 s, a second persistent kernel beside it, an uneven XCD placement) it raises a
- * flag in host-mapped memory, abandons the remaining layers, and the NEXT entry point called on the context (smk_template /
- * smk_track / smk_refine / smk_step / smk_seq_status) returns SMK_E_HIP: the results enqueued since then are invalid,
+ * flag in host-mapped memory, abandons the remaining layers, and smk_seq_sync_check behind the call -- or, for callers that do
+ * not use it, the NEXT entry point called on the context (smk_template / smk_track / smk_refine / smk_step /
+ * smk_seq_status) -- returns SMK_E_HIP: the results enqueued since then are invalid,
  * sequences are switched off for the context (per-layer kernels from there on) and the caller re-submits the frame.
  * smk_seq_status synchronises the device and reports: grid_out = workgroups per launch (0: sequences are off -- the
  * placement / occupancy check at smk_create failed, or a failure was reported); err_out = last failure (0 none,
  * 1 placement violated, 2 barrier time-out).  Returns non-zero when a failure has been reported. */
 int smk_seq_status(smk_ctx *ctx, int *grid_out, int *err_out);
+/* The same check scoped to ONE call: when a sequence launch has been enqueued on the context since the flag was last looked at,
+ * synchronise `stream` (the stream the entry points were given) and read the flag -- a failure is returned by the call that
+ * produced the invalid frame, not by the next one.  Costs nothing (no synchronisation) when no sequence launch is pending.
+ * Callers that read results right behind the call (the reference's tools do: tools/test.py:205 `.cpu()`) call it where they
+ * would synchronise anyway; siammask_amd.custom does so in template / track / track_mask / track_refine and re-runs the frame
+ * on the per-layer kernels.  synced_out (may be NULL): 1 when the stream was synchronised. */
+int smk_seq_sync_check(smk_ctx *ctx, void *stream, int *synced_out);
 
 /* capture the launch sequences into hipGraphs and replay them (on by default when the
  * environment variable SMK_GRAPH is not "0"); graphs are keyed on (entry, batch, flags,

@@ -60,6 +60,11 @@ int smk_profile_dump(smk_ctx *ctx, char *json_buf, int capacity);
 /* read back an internal activation as f32 NCHW into a device buffer (parity tests only).
  * names: "p0","p1","p2","p3","search","zf","zk","xs","corr","head0"; batch = last batch.
  * *numel_out receives C*H*W per item; dst may be NULL to query the shape (c,h,w). */
+/* test aid: raise the persistent sequence kernel's failure flag (device + host-mapped copy) exactly as the kernel does
+ * (code 1 = uneven XCD placement, 2 = team-barrier time-out): the next sequence launch finds it set and returns at once, so
+ * the failure path (smk_seq_sync_check, the fall-back to the per-layer kernels, siammask_amd.custom's transparent re-run)
+ * can be exercised without provoking a real time-out. */
+int smk_debug_seq_inject(smk_ctx *ctx, int code);
 int smk_debug_read(smk_ctx *ctx, const char *name, float *dst_dev, int *c, int *h, int *w,
                    void *stream);
 

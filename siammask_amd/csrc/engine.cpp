@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -242,6 +243,7 @@ struct smk_ctx {
     // arena (sized for maxB)
     std::map<std::string, void *> buf;
     std::map<std::string, size_t> buf_elems;  // per item
+    std::set<std::string> buf_alias;          // names that share another entry's allocation (never freed themselves)
     int *pos_dev = nullptr;
     void *dec_scratch = nullptr;     // decode: per-stream winners of the A workgroups + arrival counters
     float *ks_part = nullptr;        // split-K: f32 partial tiles (KS_PART_FLOATS) and per-tile arrival counters
@@ -252,6 +254,9 @@ struct smk_ctx {
     int *seq_err_host = nullptr;     // the same flag in host-mapped pinned memory: read at every entry point without a sync
     int *seq_err_hdev = nullptr;     // device address of seq_err_host
     int seq_fail = 0;                // last failure code taken from the flag (sticky, reported by smk_seq_status)
+    bool seq_pending = false;        // a sequence launch has been enqueued since the flag was last checked behind a synchronisation
+    bool cap_has_seq = false;        // the graph being captured contains a sequence launch
+    std::map<GraphKey, bool> graph_has_seq;
     unsigned long long *seq_clk = nullptr, *seq_clk2 = nullptr;   // SMK_SEQ_CLK stamps (measurement aid), per context
     int seq_grid = 0;                // workgroups of a sequence launch (= CUs) when the placement check passed, else 0
     bool seq_on = false;             // run_conv records into seq_rec instead of launching
@@ -529,18 +534,22 @@ static int build_arena(smk_ctx *c) {
     CHK(alloc_buf(c, "p1", 63 * 63 * 256));
     // layer2 / layer3 have their OWN intermediates, one layout per buffer (run_backbone): inside the persistent sequence the eight
     // teams are not synchronised with each other, and a buffer that changes its image pitch between layers lets a team that is ahead
-    // write over the images of a team that is behind (found at B = 9..14: profiles/r03h_b12_race.txt)
-    CHK(alloc_buf(c, "t1_s", 63 * 63 * 128));        // layer2.0 conv1 output (in front of the stride-2 conv2)
-    CHK(alloc_buf(c, "t1_2", 31 * 31 * 128));
-    CHK(alloc_buf(c, "t2_2", 31 * 31 * 128));
-    CHK(alloc_buf(c, "r_2", 31 * 31 * 512));
-    CHK(alloc_buf(c, "a_2", 31 * 31 * 512));
-    CHK(alloc_buf(c, "b_2", 31 * 31 * 512));
-    CHK(alloc_buf(c, "t1_3", 31 * 31 * 256));
-    CHK(alloc_buf(c, "t2_3", 31 * 31 * 256));
-    CHK(alloc_buf(c, "r_3", 31 * 31 * 1024));
-    CHK(alloc_buf(c, "a_3", 31 * 31 * 1024));
-    CHK(alloc_buf(c, "b_3", 31 * 31 * 1024));
+    // write over the images of a team that is behind (found at B = 9..14: profiles/r03h_b12_race.txt).  Only f16 contexts can run
+    // the sequence kernel; an f32 context launches layer after layer on one stream, where re-using a / b / t1 / t2 / r is safe, so
+    // there the stage-private names are ALIASES of the shared buffers (5.7 M elements per image saved: 1.45 GB at max_batch 64).
+    static const char *STAGE_PRIV[][2] = {{"t1_s", "t1"}, {"t1_2", "t1"}, {"t2_2", "t2"}, {"r_2", "r"}, {"a_2", "a"}, {"b_2", "b"},
+                                          {"t1_3", "t1"}, {"t2_3", "t2"}, {"r_3", "r"}, {"a_3", "a"}, {"b_3", "b"}};
+    static const size_t STAGE_PRIV_ELEMS[] = {63 * 63 * 128, 31 * 31 * 128, 31 * 31 * 128, 31 * 31 * 512, 31 * 31 * 512, 31 * 31 * 512,
+                                              31 * 31 * 256, 31 * 31 * 256, 31 * 31 * 1024, 31 * 31 * 1024, 31 * 31 * 1024};
+    for (size_t i = 0; i < sizeof(STAGE_PRIV) / sizeof(STAGE_PRIV[0]); ++i) {
+        if (c->dtype == DT_F16) CHK(alloc_buf(c, STAGE_PRIV[i][0], STAGE_PRIV_ELEMS[i]));
+        else {
+            if (STAGE_PRIV_ELEMS[i] > c->buf_elems.at(STAGE_PRIV[i][1])) return fail(SMK_E_STATE, "arena alias %s", STAGE_PRIV[i][0]);
+            c->buf[STAGE_PRIV[i][0]] = c->buf.at(STAGE_PRIV[i][1]);
+            c->buf_elems[STAGE_PRIV[i][0]] = STAGE_PRIV_ELEMS[i];
+            c->buf_alias.insert(STAGE_PRIV[i][0]);
+        }
+    }
     CHK(alloc_buf(c, "p2", 31 * 31 * 512));
     CHK(alloc_buf(c, "search", 31 * 31 * 256));
     CHK(alloc_buf(c, "zf", 7 * 7 * 256));
@@ -839,14 +848,26 @@ static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
     if (!a.res || a.res_mode != RES_PRE_RELU || !a.relu || b.res || b.res_mode != RES_NONE) return false;
     if (b.in != a.out || b.cin_off != a.cout_off || b.Cs != a.Cos || b.Ci != a.Nst || b.Hs != a.Ho || b.Ws != a.Wo) return false;
     if (b.out == a.out || b.out == a.res || b.out == a.in) return false;
-    // the routine fetches the residual BEFORE it waits for the team barrier behind layer i - 1: whoever wrote it inside this
-    // list must be separated from layer i by a barrier that the workgroup has already passed, i.e. one behind a layer <= i - 2
+    // The routine fetches the residual BEFORE it waits at its hoist point.  The barrier still pending there is the one behind
+    // the LAST layer before i that carries one (`pend`; layer i - 1 when it has sync = 1, an earlier one when smk_op_conv_seq's
+    // caller chained independent members with sync = 0).  Whoever wrote the residual inside this list must be separated from
+    // layer i by a barrier the workgroup has already PASSED, i.e. one behind a layer j' with writer <= j' < pend.
+    // (The first record of an already marked pair carries no barrier of its own.)
+    auto has_bar = [&](int k) { return L[k].sync && L[k].cfg != SEQ_CFG_C3C1_L3 && L[k].cfg != SEQ_CFG_C3C1_L2; };
+    int pend = -1;
+    for (int k = i - 1; k >= 0; --k)
+        if (has_bar(k)) { pend = k; break; }
     for (int j = i - 1; j >= 0; --j)
         if (L[j].out == a.res) {
             bool passed = false;
-            for (int k = j; k <= i - 2; ++k)          // (the first record of an already marked pair carries no barrier of its own)
-                passed = passed || (L[k].sync && L[k].cfg != SEQ_CFG_C3C1_L3 && L[k].cfg != SEQ_CFG_C3C1_L2);
+            for (int k = j; k < pend; ++k) passed = passed || has_bar(k);
             if (!passed) return false;
+            break;
+        }
+    // conv3's own input must be behind the pending barrier too (the hoist point is the only wait in front of its loads)
+    for (int j = i - 1; j >= 0; --j)
+        if (L[j].out == a.in) {
+            if (j > pend) return false;
             break;
         }
     if (a.Kpad == 256 && a.Nst == 1024 && b.Nst == 256) *code = SEQ_CFG_C3C1_L3;
@@ -956,6 +977,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         }
         if (launch_conv_seq(a, c->seq_grid, s))
             return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
+        c->seq_pending = c->cap_has_seq = true;          // (smk_seq_sync_check: the flag is worth a look once this has drained)
         if (want_clk) {                                  // per-layer spans of (team 0, slot 0), eager mode only
             unsigned long long h[2 * SEQ_MAX + 1], h2[12 * SEQ_MAX];
             HIPCHK(hipStreamSynchronize(s));
@@ -988,6 +1010,8 @@ static int seq_health(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
+    c->graph_has_seq.clear();
+    c->seq_pending = false;
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
     return fail(SMK_E_HIP, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
@@ -1549,7 +1573,11 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
     if (it == c->graphs.end()) {
         if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
         HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        const bool pend0 = c->seq_pending;
+        c->cap_has_seq = false;
         int rc = body(c->cap_stream);
+        const bool has_seq = c->cap_has_seq;
+        c->seq_pending = pend0;                          // captured, not enqueued
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
@@ -1567,12 +1595,15 @@ static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&b
                 if (u->second < lru->second) lru = u;
             auto g = c->graphs.find(lru->first);
             if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
+            c->graph_has_seq.erase(lru->first);
             c->graph_used.erase(lru);
         }
         it = c->graphs.emplace(key, ex).first;
+        c->graph_has_seq[key] = has_seq;
     }
     c->graph_used[key] = ++c->graph_tick;
     HIPCHK(hipGraphLaunch(it->second, s));
+    if (c->graph_has_seq[key]) c->seq_pending = true;
     return 0;
 }
 
@@ -1604,7 +1635,7 @@ static int seq_grid_for(int ncu) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 3; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
+int smk_version(void) { return (1 << 16) | 4; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
                                                   // sequence failures reported at the next entry point
 
 const char *smk_last_error(void) { return g_err.c_str(); }
@@ -1654,7 +1685,8 @@ int smk_destroy(smk_ctx *c) {
     hipSetDevice(c->device);
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
-    for (auto &kv : c->buf) hipFree(kv.second);
+    for (auto &kv : c->buf)
+        if (!c->buf_alias.count(kv.first)) hipFree(kv.second);
     for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
@@ -1836,6 +1868,17 @@ int smk_seq_status(smk_ctx *c, int *grid, int *err) {
         return fail(SMK_E_STATE, "conv_seq_kernel reported %s earlier; persistent sequences are off for this context",
                     c->seq_fail == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out");
     return 0;
+}
+
+int smk_seq_sync_check(smk_ctx *c, void *stream, int *synced) {
+    if (synced) *synced = 0;
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    if (!c->seq_pending) return 0;                       // no sequence launch in flight: nothing to wait for, nothing to check
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (synced) *synced = 1;
+    c->seq_pending = false;
+    return seq_health(c);
 }
 
 int smk_set_graph_mode(smk_ctx *c, int enable) {
@@ -2120,6 +2163,15 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
     return 0;
 }
 
+int smk_debug_seq_inject(smk_ctx *c, int code) {
+    if (!c || !c->seq_err || !c->seq_err_host) return fail(SMK_E_ARG, "smk_debug_seq_inject: no context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c->seq_err, &code, sizeof(int), hipMemcpyHostToDevice));
+    *(volatile int *)c->seq_err_host = code;
+    return 0;
+}
+
 int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int *W, void *stream) {
     if (!c || !name) return fail(SMK_E_ARG, "smk_debug_read: null argument");
     const int nbt = nbranch(c);
@@ -2241,6 +2293,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     if (mode == 4) {                                   // halo kernel (3x3 stride 1), BM from the tile code
         o.halo = (o.tile_code & 15) == 1 ? 128 : 64;
         CHK(upload_halo_pack(pc, rows, dtype));
+        if (pc.w_frag_halo) tmp.v.push_back(pc.w_frag_halo);     // (f16: upload_halo_pack also makes the fragment-order copy)
         if (!pc.w_halo) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry is not eligible for the halo kernel");
         tmp.v.push_back(pc.w_halo);
     }

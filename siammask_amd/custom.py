@@ -107,6 +107,8 @@ class Custom(nn.Module):
         self._hp = None
         self._hp_dirty = True
         self.zf = None          # reference attribute (custom.py:174); opaque handle here
+        self._replay = {}       # what a failed persistent-sequence launch needs to be re-run (see _guarded)
+        self.seq_recovered = 0  # frames re-run on the per-layer kernels after a reported sequence failure
 
     # -- weights --------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -258,6 +260,33 @@ class Custom(nn.Module):
             return self._buf(key, shape, device, dtype)
         return torch.empty(shape, dtype=dtype, device=device)
 
+    # -- a persistent-sequence failure is reported by the call that produced the invalid frame -------------------
+    def _guarded(self, stage, run):
+        """Enqueue one entry point of the reference surface (``run``) and, when it contained a launch of the persistent
+        per-XCD sequence kernel, wait for it and read the kernel's failure flag (smk_seq_sync_check: a stream synchronisation
+        exactly where the reference's callers synchronise anyway -- tools/test.py:205 `.cpu()` -- and nothing at all for
+        batches that do not use the sequence).  On a reported failure the library has already switched this context to the
+        per-layer kernels and dropped the cached template; the frame is re-run transparently from the inputs kept in
+        ``self._replay`` (template -> track -> refine as far as ``stage`` needs), so the caller never sees an invalid frame
+        and never an exception it would have to answer with a re-submit."""
+        L = _lib.lib()
+
+        def once():
+            run()
+            _lib.check(L.smk_seq_sync_check(self._ctx, _lib.current_stream_ptr(), None))
+        try:
+            return once()
+        except _lib.SmkError as e:
+            # (raised by the check behind the call, or by the entry point itself when an earlier, unguarded call -- the
+            #  asynchronous track_step -- left the flag set)
+            if "conv_seq_kernel reported" not in str(e):
+                raise
+        self.seq_recovered += 1
+        order = ("template", "track", "refine")
+        for st in order[:order.index(stage)]:
+            self._replay[st]()
+        once()
+
     # -- the reference surface ------------------------------------------------------------------
     def template(self, template):
         """custom.py:173-174 -- caches the template features (and conv_kernel(zf)) on device."""
@@ -265,7 +294,13 @@ class Custom(nn.Module):
         self._ensure(template, B, grow=True)
         with torch.cuda.device(self._ctx_device):
             z = self._stage_in("z", template, spec.TEMPLATE_SIZE)
-            _lib.check(_lib.lib().smk_template(self._ctx, z.data_ptr(), B, _lib.current_stream_ptr()))
+            if not self._graph:
+                z = z.clone()        # kept for a re-run (the staged buffer of graph mode is ours already)
+
+            def run():
+                _lib.check(_lib.lib().smk_template(self._ctx, z.data_ptr(), B, _lib.current_stream_ptr()))
+            self._replay = {"template": run}
+            self._guarded("template", run)
         self.zf = ("device-resident", B)
         self._tracked = 0
 
@@ -284,9 +319,12 @@ class Custom(nn.Module):
             mask = None
             if want_mask:
                 mask = self._out("mask", (B, spec.MASK_OUT ** 2, spec.SCORE_SIZE, spec.SCORE_SIZE), dev)
-            _lib.check(_lib.lib().smk_track(
-                self._ctx, x.data_ptr(), B, flags, cls.data_ptr(), loc.data_ptr(),
-                mask.data_ptr() if mask is not None else None, _lib.current_stream_ptr()))
+            def run():
+                _lib.check(_lib.lib().smk_track(
+                    self._ctx, x.data_ptr(), B, flags, cls.data_ptr(), loc.data_ptr(),
+                    mask.data_ptr() if mask is not None else None, _lib.current_stream_ptr()))
+            self._replay["track"] = run          # (x: the staged buffer in graph mode, else the caller's tensor -- kept alive here)
+            self._guarded("track", run)
         if self._graph:
             cls, loc = cls.clone(), loc.clone()      # small; mask stays a view of the I/O buffer
         return cls, loc, mask
@@ -480,7 +518,8 @@ class CustomSharp(CustomBase):
                 p = pos.to(torch.int32).contiguous().view(-1)
                 if p.numel() != 2 * B:
                     raise ValueError("pos tensor must have shape [B,2]")
-                _lib.check(L.smk_refine(self._ctx, p.data_ptr(), 1, B, out.data_ptr(), _lib.current_stream_ptr()))
+                self._guarded("refine", lambda: _lib.check(
+                    L.smk_refine(self._ctx, p.data_ptr(), 1, B, out.data_ptr(), _lib.current_stream_ptr())))
             else:
                 a = np.asarray(pos.cpu() if isinstance(pos, torch.Tensor) else pos, dtype=np.int32)
                 if a.ndim == 1:
@@ -488,8 +527,8 @@ class CustomSharp(CustomBase):
                 if a.shape != (B, 2):
                     raise ValueError("pos must be (y, x) or [B,2]")
                 a = np.ascontiguousarray(a)
-                _lib.check(L.smk_refine(self._ctx, a.ctypes.data_as(ctypes.c_void_p), 0, B, out.data_ptr(),
-                                        _lib.current_stream_ptr()))
+                self._guarded("refine", lambda: _lib.check(
+                    L.smk_refine(self._ctx, a.ctypes.data_as(ctypes.c_void_p), 0, B, out.data_ptr(), _lib.current_stream_ptr())))
         return out
 
     def debug_tensor(self, name):
