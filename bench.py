@@ -266,6 +266,7 @@ def roofline(w, steps=3):
                                 "launches_per_step": sum(f["calls"] for f in allc) // steps,
                                 "share_of_gpu_time": round(ms / total_ms, 4)}
     out["launches_per_step_all_kernels"] = sum(f["calls"] for f in fam.values()) // steps
+    out["kernels"] = kernel_table(recs, steps, peak)
     # HBM bytes per launch from the PMC counters (collected offline by tools/measure/gpu_pmc.sh with rocprofv3
     # --pmc in separate passes and committed under profiles/; cannot be sampled from inside this process)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % w.name)
@@ -290,6 +291,7 @@ def roofline(w, steps=3):
                     out["traffic_note"] = "bytes per launch of the per-launch conv kernels; %s; %s" % (t["source"], t["correction"])
         except Exception:  # noqa: BLE001
             pass
+    out["rocprofv3"] = rocprof_stats_for(w.name, dom)
     out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))
     if d.get("ext", 0.0) > 0:
         # conv_seq: the bytes that must cross the fabric when every tensor produced and consumed inside the launch stays in
@@ -309,6 +311,52 @@ def roofline(w, steps=3):
         except Exception:  # noqa: BLE001
             pass
     return out, recs
+
+
+def kernel_table(recs, steps, peak_tflops):
+    """One row per kernel of the step: launches per step, microseconds per step, the roofline that binds it
+    (whichever of algorithmic flops / MFMA peak and algorithmic bytes / 8 TB/s is the larger fraction) and that fraction.
+    Rows are ordered by time; `share` is the row's part of the step's kernel time."""
+    rows = {}
+    for r in recs:
+        k = r["kernel"]
+        q = rows.setdefault(k, {"ms": 0.0, "flop": 0.0, "bytes": 0.0, "calls": 0})
+        q["ms"] += r["ms"]; q["flop"] += r["flop"]; q["bytes"] += r["bytes"]; q["calls"] += r["calls"]
+    total = sum(q["ms"] for q in rows.values()) or 1.0
+    out = []
+    for k, q in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
+        t = q["ms"] * 1e-3
+        tf = q["flop"] / t / 1e12 if t > 0 else 0.0
+        gb = q["bytes"] / t / 1e9 if t > 0 else 0.0
+        mf, hf = tf / peak_tflops, gb / 8000.0
+        row = {"kernel": k, "launches": round(q["calls"] / steps, 2), "us_per_step": round(q["ms"] * 1e3 / steps, 2),
+               "share": round(q["ms"] / total, 4), "bound": "mfma" if mf >= hf else "hbm",
+               "achieved": round(tf if mf >= hf else gb, 1), "unit": "TFLOP/s" if mf >= hf else "GB/s", "frac": round(max(mf, hf), 4)}
+        out.append(row)
+    return out
+
+
+def rocprof_stats_for(workload, dom):
+    """rocprofv3 --kernel-trace --stats summary of the same command (profiles/rocprofv3_kernel_stats_<workload>.json, written by
+    the round's final script from the CSV): attached only when it was measured on exactly these kernel sources (sha256), like
+    the PMC traffic summary -- a stale profile is refused, not quoted."""
+    path = os.path.join(REPO, "profiles", "rocprofv3_kernel_stats_%s.json" % workload)
+    if not os.path.exists(path):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tools", "measure"))
+        from src_hash import kernel_sources_sha256
+        t = json.load(open(path))
+        if t.get("kernel_sources_sha256") != kernel_sources_sha256():
+            return {"note": "profiles/%s was measured on other kernel sources (sha256 %s...): refused; re-run the round's final script"
+                            % (os.path.basename(path), str(t.get("kernel_sources_sha256"))[:12])}
+        for row in t.get("kernels", []):
+            if dom in row["name"]:
+                return {"kernel": row["name"], "calls": row["calls"], "avg_us": row["avg_us"], "share": row.get("percentage"),
+                        "file": "profiles/" + os.path.basename(path), "kernel_sources_sha256": t["kernel_sources_sha256"][:12]}
+    except Exception as e:  # noqa: BLE001
+        return {"note": "unreadable: %s" % str(e)[:120]}
+    return None
 
 
 def cpu_model_string():
@@ -395,6 +443,96 @@ def cpu_baseline(budget_s=10.0):
                       "a short scan) on %d logical CPUs, %s" % (what, n8, e8, thr8, n1, e1, best_thr, ncpu, cpu_model_string())}
 
 
+def vendor_baseline_guarded(timeout_s=150):
+    """vendor_baseline in a child process with a hard time limit (MIOpen may compile kernels for shapes it has no binary for:
+    that must never cost the contract line its few-minutes budget); rows measured before the limit are kept."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--vendor-leg"]
+    rows, what, note = {}, None, None
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, universal_newlines=True)
+        text = p.stdout
+    except subprocess.TimeoutExpired as e:
+        text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = "stopped after %d s (rows measured until then are kept)" % timeout_s
+    for ln in text.splitlines():
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if "row" in d:
+                rows[d["row"]] = d["result"]
+            elif "what" in d:
+                what = d["what"]
+            elif "error" in d:
+                note = d["error"]
+    out = {"what": what, "rows": rows}
+    if note:
+        out["note"] = note
+    return out
+
+
+def vendor_baseline(dev, budget_s=2.0, stream=False):
+    """The UNMODIFIED reference `Custom` (experiments/siammask_sharp/custom.py:173-190, from oracle/_ref) on THIS GPU through
+    PyTorch-ROCm (MIOpen / rocBLAS): the same-node vendor-library row of SURVEY.md 8c/8d -- what a user of the reference gets
+    on an MI355X by calling `.cuda()`, beside what this library does.  fp32 and `.half()`, B = 1 / 8 / 64, track_mask +
+    track_refine per step (the reference's own call sequence: two host round trips per frame are part of it; the position is
+    fixed so that no host decode is timed).  A reported baseline like cpu_baseline, never the thing measured."""
+    def emit(d):
+        if stream:
+            print(json.dumps(d), flush=True)
+    ref = cpu_reference_model()
+    if ref is None:
+        emit({"error": "oracle/_ref not present"})
+        return {"error": "oracle/_ref not present (built by __graft_entry__.build() where /root/reference exists)"}
+    out = {"what": "reference Custom (oracle/_ref, unmodified) on cuda via PyTorch-ROCm %s / MIOpen, track_mask + track_refine((12,12)), "
+                   "eager, synchronised per batch of iterations" % torch.__version__, "rows": {}}
+    emit({"what": out["what"]})
+    for dname, conv in (("f32", lambda m: m.float()), ("f16", lambda m: m.half())):
+        try:
+            m = conv(ref).to(dev)
+        except Exception as e:  # noqa: BLE001
+            out["rows"][dname] = {"error": str(e)[:160]}
+            continue
+        tdt = torch.float32 if dname == "f32" else torch.float16
+        for B in (1, 8, 64):
+            key = "%s_b%d" % (dname, B)
+            try:
+                z = torch.from_numpy(synth.image_batch(B, 127, stream0=0)).to(dev, tdt)
+                x = torch.from_numpy(synth.image_batch(B, 255, stream0=1000)).to(dev, tdt)
+                with torch.no_grad():
+                    m.template(z)
+                    for _ in range(3):                     # MIOpen solution search / workspace allocation happen here
+                        m.track_mask(x); m.track_refine((12, 12))
+                    torch.cuda.synchronize(dev)
+                    n, t0 = 0, time.perf_counter()
+                    while True:
+                        for _ in range(5):
+                            m.track_mask(x); r = m.track_refine((12, 12))
+                        torch.cuda.synchronize(dev)
+                        n += 5
+                        el = time.perf_counter() - t0
+                        if el >= budget_s or n >= 400:
+                            break
+                out["rows"][key] = {"fps": round(B * n / el, 1), "ms_per_step": round(el / n * 1e3, 3), "steps": n}
+                del z, x, r
+            except Exception as e:  # noqa: BLE001
+                out["rows"][key] = {"error": str(e)[:160]}
+            emit({"row": key, "result": out["rows"][key]})
+        ref = ref.float().cpu()
+        torch.cuda.empty_cache()
+    return out
+
+
+def argmax_agreement(B=64, seeds=8):
+    """fp16 best-anchor index vs the fp32 (pinned) path over B x seeds x 2 input kinds streams, product path only
+    (tools/measure/argmax_stats.py; the gate with gaps and errors is tests/test_gpu_argmax.py)."""
+    sys.path.insert(0, os.path.join(REPO, "tools", "measure"))
+    import argmax_stats
+    return argmax_stats.summary(argmax_stats.collect(B=B, seeds=seeds))
+
+
 def free_port():
     import socket
     so = socket.socket()
@@ -439,6 +577,40 @@ def check_world(args, world, dev):
         raise SystemExit("--gpus %d but the all_gather of rank ids returned %s" % (args.gpus, got))
 
 
+def dry_run(args, rank, local, world, dev, place):
+    """`bench.py --gpus N --dry-run`: no timing -- what a first 8-GPU run could trip over, checked per rank and printed by rank 0:
+    the device each rank drives, its CU count, whether the XCD census of smk_create admits the persistent sequence kernel (256
+    workgroups: 8 XCDs x 32 CUs, SPX mode), its PCI address / NUMA node / CPU affinity, and that an all_gather over the backend
+    returns every rank's report."""
+    rep = {"rank": rank, "local_rank": local, "host_placement": place, "pid": os.getpid()}
+    if not args.stub:
+        import ctypes
+        from siammask_amd import _lib
+        p = torch.cuda.get_device_properties(dev)
+        rep.update({"device": dev.index, "name": p.name, "arch": getattr(p, "gcnArchName", "?"), "cus": p.multi_processor_count,
+                    "hbm_gb": round(p.total_memory / 2 ** 30, 1)})
+        ctx = ctypes.c_void_p()
+        _lib.check(_lib.lib().smk_create(ctypes.byref(ctx), dev.index, _lib.DTYPE["f16"], _lib.VARIANT["sharp"], 8))
+        g, e = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.lib().smk_seq_status(ctx, ctypes.byref(g), ctypes.byref(e))
+        _lib.lib().smk_destroy(ctx)
+        rep["persistent_sequence_workgroups"] = g.value       # 0: census / occupancy check failed -> per-layer kernels on this rank
+        rep["sequence_ok"] = g.value == p.multi_processor_count and g.value % 8 == 0
+    reports = [rep]
+    if world > 1:
+        import torch.distributed as dist
+        reports = [None] * world
+        dist.all_gather_object(reports, rep)
+    if rank == 0:
+        devs = [r.get("device") for r in reports]
+        line = {"dry_run": True, "n_gpus": world, "ranks": reports,
+                "distinct_devices": args.stub or len(set(devs)) == world,
+                "all_sequences_ok": args.stub or all(r.get("sequence_ok") for r in reports)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -447,7 +619,8 @@ def main():
     ap.add_argument("--workload", default="sharp_b8_f16", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads (B=1 fp32, ...)")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads (B=1 fp32, ...), the argmax statistic and the vendor baseline")
+    ap.add_argument("--no-long", action="store_true", help="skip the 200-step repeat of the timed loop")
     ap.add_argument("--prewarm-seconds", type=float, default=2.0,
                     help="untimed clock/cache warm-up before the W warm-up steps")
     ap.add_argument("--unfused", action="store_true",
@@ -458,8 +631,16 @@ def main():
     ap.add_argument("--profile-out", default="", help="write the per-layer launch profile (JSON) here")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test on CPU (gloo, no kernels): see StubWorkload; not a measurement")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="placement report instead of a measurement: every rank prints its device, CU count, XCD census "
+                         "(is the persistent sequence kernel usable there?), PCI / NUMA node and CPU affinity; rank 0 prints one JSON line")
+    ap.add_argument("--vendor-leg", action="store_true", help=argparse.SUPPRESS)     # child process of vendor_baseline_guarded
     args = ap.parse_args()
 
+    if args.vendor_leg:
+        os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")      # immediate-mode solutions: no exhaustive search per shape
+        vendor_baseline(torch.device("cuda", 0), stream=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
 
@@ -477,6 +658,13 @@ def main():
         dev = torch.device("cuda", local if world > 1 else 0)
         torch.cuda.set_device(dev)
     check_world(args, world, dev)
+    place = None
+    if world > 1 or args.dry_run:
+        # one process per GPU: run next to it (CPUs of the GPU's NUMA node; siammask_amd/dist.py rank_cpus)
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        place = sdist.pin_rank(local, n_local, None if args.stub else dev.index)
+    if args.dry_run:
+        return dry_run(args, rank, local, world, dev, place)
     gather = sdist.ResultGather(dev)
 
     if args.stub:
@@ -489,6 +677,14 @@ def main():
     main_timing = dict(w.last_timing)
     frames = w.B * world * args.steps
     fps = frames / dt
+    # the same loop over 200 steps beside the driver's 20 (12 ms of GPU time is thin on a fleet whose boxes differ by +-12 %):
+    # reported next to `value`, never instead of it
+    long_run = None
+    if not args.stub and world == 1 and args.steps < 200 and not args.no_long:
+        res200 = Results(w, 200)
+        d200 = timed_run(w, 200, 5, 1, gather, res200)
+        long_run = {"steps": 200, "value": round(w.B * 200 / d200, 2), "ms_per_step": round(d200 / 200 * 1e3, 4)}
+        del res200
 
     seq = None
     if not args.stub:
@@ -532,6 +728,20 @@ def main():
             except Exception as e:  # secondary numbers must never kill the contract line
                 also[name] = {"error": str(e)[:200]}
 
+    agree = vendor = None
+    if rank == 0 and world == 1 and not args.no_also and not args.stub:
+        del w.model
+        torch.cuda.empty_cache()
+        try:
+            agree = argmax_agreement()
+        except Exception as e:  # noqa: BLE001
+            agree = {"error": str(e)[:200]}
+        torch.cuda.empty_cache()
+        try:
+            vendor = vendor_baseline_guarded()
+        except Exception as e:  # noqa: BLE001
+            vendor = {"error": str(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub:
         try:
@@ -556,8 +766,11 @@ def main():
                        "step": ("track_mask -> device decode -> track_refine, one graph" if w.fused
                                 else "track_mask ; track_refine(fixed pos)"),
                        "gflop_per_frame": w.gflop_per_frame()},
+            "value_200_steps": long_run,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "vendor_baseline": vendor,
+            "argmax_agreement": agree,
             "tflops_end_to_end": round(fps / world * w.gflop_per_frame() / 1e3, 2),
             "timing": main_timing,
             "also": also or None,

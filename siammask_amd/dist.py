@@ -27,6 +27,68 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+# ---- host placement of a rank (one process per GPU): CPU affinity next to the GPU's NUMA node --------------------------------
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(pci_bus_id, sysfs="/sys"):
+    """NUMA node of a PCI device ('0000:c1:00.0') from sysfs, or -1 when the platform does not say."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def rank_cpus(local_rank, n_local, pci_bus_id=None, allowed=None, sysfs="/sys"):
+    """The CPUs a rank should run on.  The reference's scale-out is one process per GPU too (experiments/siammask_sharp/
+    test_all.sh:68,77) and leaves placement to the OS; on an 8-GPU node with 2 sockets that lets a rank's host thread -- which
+    enqueues a graph every 0.6 ms -- run a socket away from its GPU.  Rule: the CPUs of the GPU's NUMA node (sysfs), split
+    evenly among the local ranks that share that node when several do (their order is their local rank); without NUMA
+    information an even contiguous share of the allowed CPUs.  Never returns an empty set."""
+    allowed = set(allowed if allowed is not None else os.sched_getaffinity(0))
+    node = gpu_numa_node(pci_bus_id, sysfs) if pci_bus_id else -1
+    if node >= 0:
+        try:
+            with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+                cpus = _parse_cpulist(f.read()) & allowed
+            if cpus:
+                return cpus, node
+        except OSError:
+            pass
+    order = sorted(allowed)
+    share = max(1, len(order) // max(1, n_local))
+    lo = (local_rank % max(1, n_local)) * share
+    return set(order[lo:lo + share]) or set(order), -1
+
+
+def pin_rank(local_rank, n_local, device_index=None):
+    """Apply rank_cpus() to this process (SMK_NO_AFFINITY=1 leaves placement alone).  -> dict for the dry-run report."""
+    bdf = None
+    if device_index is not None and torch.cuda.is_available():
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        except Exception:  # noqa: BLE001
+            bdf = None
+    cpus, node = rank_cpus(local_rank, n_local, bdf)
+    pinned = False
+    if os.environ.get("SMK_NO_AFFINITY", "0") != "1":
+        try:
+            os.sched_setaffinity(0, cpus)
+            pinned = True
+        except OSError:
+            pinned = False
+    return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "cpu_first": min(cpus), "cpu_last": max(cpus), "pinned": pinned}
+
+
 def shard_streams(n_streams, rank, world):
     """Round-robin assignment of stream ids to ranks -> list of global stream ids of `rank`."""
     return list(range(rank, n_streams, world))
@@ -45,15 +107,18 @@ class ResultGather(object):
     The inputs must be PRIVATE result buffers (bench.py's Results rows), not the views `track_step` returns: those
     alias the persistent graph I/O buffers, which the next frame overwrites while the side-stream gather still reads."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, always_collective=False):
         self.device = device
+        # world 1 normally needs no exchange; always_collective sends it through the backend anyway (a 1-rank RCCL all_gather
+        # on the side stream): the overlap of the gather with the next batch of frames can then be exercised on ONE GPU
+        self.always_collective = always_collective
         self.side = torch.cuda.Stream(device=device) if (device is not None and device.type == "cuda") else None
         self._pending = []
 
     def gather(self, *tensors):
         world = dist.get_world_size() if dist.is_initialized() else 1
         outs = []
-        if world == 1:
+        if world == 1 and not (self.always_collective and dist.is_initialized()):
             return [t.unsqueeze(0) for t in tensors]
         if self.side is not None:
             cur = torch.cuda.current_stream(self.device)

@@ -51,3 +51,16 @@ def test_single_rank_stub_line():
     r = _run(["--stub", "--steps", "3", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert _json_line(r.stdout)["n_gpus"] == 1
+
+
+def test_dry_run_reports_every_rank_and_its_host_placement():
+    """`--gpus 2 --dry-run`: no measurement; rank 0 prints ONE line with both ranks' reports, each with a
+    non-empty CPU set (siammask_amd/dist.py pin_rank) -- what a first multi-GPU run could fail on is visible before it is timed"""
+    r = _run(["--stub", "--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _json_line(r.stdout)
+    assert line["dry_run"] and line["n_gpus"] == 2 and len(line["ranks"]) == 2
+    assert sorted(x["rank"] for x in line["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in line["ranks"]}) == 2
+    for x in line["ranks"]:
+        assert x["host_placement"]["cpus"] >= 1

@@ -64,3 +64,35 @@ def test_sharding_is_a_partition():
             owned = [s for r in range(world) for s in sdist.shard_streams(n, r, world)]
             assert sorted(owned) == list(range(n))
             assert all(sdist.stream_owner(s, world) == r for r in range(world) for s in sdist.shard_streams(n, r, world))
+
+
+def test_rank_cpus_follow_the_gpus_numa_node(tmp_path):
+    """8 ranks on a 2-socket node: every rank gets the CPUs of ITS GPU's NUMA node (sysfs), never an empty set; without
+    NUMA information an even contiguous share of the allowed CPUs (siammask_amd/dist.py rank_cpus)."""
+    sysfs = tmp_path
+    for node, cpulist in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        d = sysfs / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpulist + "\n")
+    bdfs = ["0000:%02x:00.0" % b for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+    for i, b in enumerate(bdfs):
+        d = sysfs / "bus" / "pci" / "devices" / b
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % (0 if i < 4 else 1))
+    allowed = set(range(256))
+    for r, b in enumerate(bdfs):
+        cpus, node = sdist.rank_cpus(r, 8, b, allowed, str(sysfs))
+        assert node == (0 if r < 4 else 1)
+        assert cpus == (set(range(0, 64)) | set(range(128, 192)) if r < 4 else set(range(64, 128)) | set(range(192, 256)))
+    # a cgroup that only allows part of the node: intersected, still non-empty
+    cpus, node = sdist.rank_cpus(0, 8, bdfs[0], set(range(8, 24)), str(sysfs))
+    assert cpus == set(range(8, 24)) and node == 0
+    # no NUMA information (numa_node = -1 / no sysfs entry): even contiguous shares that partition the allowed set
+    seen = set()
+    for r in range(8):
+        cpus, node = sdist.rank_cpus(r, 8, "0000:aa:00.0", allowed, str(sysfs))
+        assert node == -1 and len(cpus) == 32 and not (cpus & seen)
+        seen |= cpus
+    assert seen == allowed
+    cpus, _ = sdist.rank_cpus(5, 8, None, {3}, str(sysfs))           # fewer CPUs than ranks: everybody gets what there is
+    assert cpus == {3}

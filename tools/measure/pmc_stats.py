@@ -1,4 +1,7 @@
-"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel name (sum over dispatches)."""
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel name (sum over dispatches).
+A counter that is collected in SEVERAL passes (GRBM_GUI_ACTIVE rides in all of them) is summed over all of them, so its
+dispatch count is the number of (pass, dispatch) instances -- round 3 counted unique dispatch ids, which made
+GRBM_GUI_ACTIVE per dispatch 3x too large and `mfma_util_est` 3x too small."""
 import collections
 import csv
 import glob
@@ -13,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(root, "pass*", "*", "*counter_collection.
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        ndisp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+        ndisp[(k, r["Counter_Name"])].add((f, r["Dispatch_Id"]))
 out = {}
 for k, cs in agg.items():
     out[k] = {c: {"sum": v, "dispatches": len(ndisp[(k, c)])} for c, v in cs.items()}
