@@ -225,11 +225,12 @@ CONV_KERNELS = ("conv_igemm", "conv3x3_halo", "conv_wreg")
 MFMA_CONV = CONV_KERNELS + ("conv_seq",)                 # + the persistent per-XCD sequence kernel (its own roofline entry)
 
 
-def roofline(w, steps=3):
+def roofline(w, steps=3, mode=2):
     """Per-launch HIP-event timing of every kernel (library profiler, eager launches on the
-    current stream) -> achieved TFLOP/s of the dominant kernel family."""
+    current stream) -> achieved TFLOP/s of the dominant kernel family.  mode 2: the launch structure of the timed graph
+    (merged launches stay merged); mode 1: per-layer attribution (--profile-out)."""
     m = w.model
-    m.profile(True)
+    m.profile(mode)
     for i in range(steps):
         w.step(i)
     recs = m.profile_dump()
@@ -705,6 +706,10 @@ def main():
         except Exception as e:  # the profiler pass must never cost the contract line its `value`
             roof, recs = {"error": str(e)[:200]}, []
     if args.profile_out and rank == 0:
+        try:
+            _, recs = roofline(w, mode=1)             # per-layer attribution for the layer table
+        except Exception:  # noqa: BLE001
+            pass
         with open(args.profile_out, "w") as f:
             json.dump({"workload": args.workload, "batch": w.B, "dtype": w.dtype, "layers": recs}, f, indent=1)
 

@@ -53,7 +53,10 @@ int smk_tune_get(const char *key, int *value);
  * stream it is launched on (graph replay is bypassed while profiling).  smk_profile_dump
  * synchronises the device and writes a JSON array, one object per layer id in launch order:
  *   {"id","kernel","calls","ms" (sum of event durations),"flop","bytes"} where flop/bytes are
- * the ALGORITHMIC work of those launches (2*M*N*K; tensors read/written once), then resets. */
+ * the ALGORITHMIC work of those launches (2*M*N*K; tensors read/written once), then resets.
+ * enable = 1: per-LAYER attribution (a launch that merges several independent convolutions is split into its members);
+ * enable = 2: per-LAUNCH attribution -- the launch structure of the timed path is kept (one record per merged launch, its
+ * id the members' ids joined by '+'): what bench.py's per-kernel roofline table is made of. */
 int smk_profile(smk_ctx *ctx, int enable);
 int smk_profile_dump(smk_ctx *ctx, char *json_buf, int capacity);
 

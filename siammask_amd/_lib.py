@@ -14,7 +14,8 @@ import subprocess
 import torch  # noqa: F401  (must precede CDLL, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiammask_hip.so")
+# SMK_LIB=<path>: load another build of the library (measurement aid: A/B arms of compile-time choices, tools/measure/build_variant.sh)
+LIB_PATH = os.environ.get("SMK_LIB") or os.path.join(_HERE, "libsiammask_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "half": 1}

@@ -282,6 +282,7 @@ struct smk_ctx {
 
     // per-launch profiling (smk_profile): HIP events around every kernel, eager mode only
     bool prof = false;
+    bool prof_merge = false;         // smk_profile(ctx, 2): keep the merged launches of the timed path (attribution per LAUNCH, not per layer)
     struct ProfRec { std::string id, kernel; double flop, bytes; hipEvent_t e0, e1; double ext_bytes = 0.0; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -1174,21 +1175,46 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
         if (bm) ++n_halo;
         if (bm == 64 || (bm == 0 && cb.p[i].kh == 3)) split_for_halo = false;
     }
-    if (c->prof || cb.n == 1 || !g_tune.merge || (split_for_halo && n_halo)) {   // per-layer attribution while profiling
+    if ((c->prof && !c->prof_merge) || cb.n == 1 || !g_tune.merge || (split_for_halo && n_halo)) {   // per-layer attribution while profiling (mode 1)
         for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
         return 0;
+    }
+    // (profile mode 2: one record for the merged launch, algorithmic work summed over its members as run_conv counts it)
+    double mflop = 0.0, mbytes = 0.0;
+    std::string mid;
+    if (c->prof) {
+        const size_t es = esize(c->dtype);
+        for (int i = 0; i < cb.n; ++i) {
+            const ConvParams &q = cb.p[i];
+            const PackedConv &pc = c->conv.find(jobs[i].id)->second;
+            const int ng = q.groups > 0 ? q.groups : 1;
+            const double kreal = pc.alg_k ? (double)pc.alg_k : (double)q.kh * q.kw * q.Ci;
+            mflop += 2.0 * q.M * (double)q.N * kreal * ng;
+            mbytes += (double)B * (q.ups ? q.Hs * q.Ws : (double)q.Hl * q.Wl) * q.Ci * es * ng +
+                      (double)q.M * q.N * ng * (q.out_mode == OUT_NCHW_F32 ? 4 : es) + (double)q.N * kreal * es * ng +
+                      (q.res ? (double)q.M * q.N * es : 0.0);
+            mid += (i ? "+" : "") + std::string(jobs[i].id);
+        }
     }
     {
         int wr = wreg_choice(cb.p[lead], jobs[lead].o, c->dtype);
         for (int i = 0; i < cb.n && wr; ++i)
             if (!wreg_choice(cb.p[i], jobs[i].o, c->dtype)) wr = 0;
         if (wr) {
+            char kw_[64];
+            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(c->dtype), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), cb.n);
+            ProfScope ps(c, s, mid.c_str(), kw_, mflop, mbytes);
             const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
             if (rc == 0) return 0;
+            ps.cancel();
             if (rc != 1) return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
         }
     }
     const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], c->dtype);
+    char km_[72];
+    snprintf(km_, sizeof(km_), "conv_igemm<%s,%dx%dx%d,s%d,%s,merged%d>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
+             cb.p[lead].out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc", cb.n);
+    ProfScope psm(c, s, mid.c_str(), km_, mflop, mbytes);
     if (launch_conv_mfma_batch(cb, c->dtype, t, s))
         return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
     return 0;
@@ -1447,7 +1473,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
     ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
     Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
-    const bool merged = !par && !c->prof && g_tune.merge;
+    const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge;
     if (merged) {
         // the window convs only depend on the kept backbone features and pos: one launch with deconv
         w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
@@ -2032,6 +2058,7 @@ int smk_profile(smk_ctx *c, int enable) {
         HIPCHK(hipDeviceSynchronize());
     }
     c->prof = enable != 0;
+    c->prof_merge = enable == 2;
     return 0;
 }
 

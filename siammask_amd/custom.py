@@ -461,9 +461,11 @@ class Custom(nn.Module):
 
     # -- per-launch profiling (HIP events around every kernel; bypasses graph replay) -----------
     def profile(self, enable=True):
+        """enable: False / 0 off; True / 1 per-LAYER attribution (merged launches are split into their members);
+        2 = per-LAUNCH attribution (the launch structure of the timed path, merged launches kept)"""
         if self._ctx is None:
             raise RuntimeError("profile(): run template() first")
-        _lib.check(_lib.lib().smk_profile(self._ctx, 1 if enable else 0))
+        _lib.check(_lib.lib().smk_profile(self._ctx, int(enable)))
 
     def profile_dump(self):
         """-> list of {'id','kernel','calls','ms','flop','bytes'} (algorithmic work), then resets."""
