@@ -136,6 +136,17 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
              float *cls_out, float *loc_out, float *mask_out, double *box_out, float *refine_out,
              void *stream);
 
+/* Result ring (additive; the multi-GPU flow of SURVEY.md 8e gathers boxes / masks "only at the end of a batch of frames",
+ * tools/test.py:296-311 keeps them per frame): with a ring set, every smk_step ends with ONE small launch that stores the
+ * frame's decoded box [batch][8] f64 and its Refine logits [batch][127*127] as fp16 into row (frames committed % rows) of the
+ * caller's device buffers box_ring [rows][batch][8] / refine_ring_f16 [rows][batch][127*127] and advances a device-side frame
+ * counter -- part of the captured graph, no host work, no per-frame copies by the caller.  `batch` is that of the smk_step calls
+ * (one batch size per ring).  refine_ring_f16 may be NULL (boxes only); rows = 0 switches the ring off.  Synchronises the device
+ * and drops the captured graphs.  smk_result_ring_cursor synchronises `stream`, returns the number of frames committed and
+ * optionally resets it. */
+int smk_set_result_ring(smk_ctx *ctx, double *box_ring_dev, void *refine_ring_f16_dev, int rows);
+int smk_result_ring_cursor(smk_ctx *ctx, int *frames_out, int reset, void *stream);
+
 /* persistent per-XCD convolution sequences (fp16, batch 8: ResNet layer2 / layer3 / adjust run as ONE conv_seq_kernel launch,
  * one workgroup per CU, image b on XCD b % 8).  The kernel needs every workgroup resident at once; when that fails (a
  * neighbour that holds CUs for more than 0.2 s, a second persistent kernel beside it, an uneven XCD placement) it raises a

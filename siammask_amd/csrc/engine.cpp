@@ -268,6 +268,12 @@ struct smk_ctx {
     std::vector<std::string> seq_ids;
     double seq_flop = 0.0, seq_bytes = 0.0;
 
+    // result ring (smk_set_result_ring): caller-owned rows, library-owned cursor
+    double *ring_box = nullptr;
+    void *ring_ref = nullptr;
+    int ring_rows = 0;
+    int *ring_cursor = nullptr;      // device [2]: [0] frames committed, [1] arrival counter of ring_commit_kernel
+
     // decode (tools/test.py:205-254 on device)
     float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
     int anchor_stride = 8;
@@ -1724,6 +1730,7 @@ int smk_destroy(smk_ctx *c) {
     if (c->seq_clk) hipFree(c->seq_clk);
     if (c->seq_clk2) hipFree(c->seq_clk2);
     if (c->window_dev) hipFree(c->window_dev);
+    if (c->ring_cursor) hipFree(c->ring_cursor);
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->side[i]) hipStreamDestroy(c->side[i]);
@@ -2183,10 +2190,43 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
             c->mask_join_pending = false;
             CHK(stream_dep(c, c->side[0], st));
         }
+        if (c->ring_rows > 0) {                      // keep this frame's results for the end-of-batch gather (smk_set_result_ring)
+            RingParams rg{box_out, refine_out, c->ring_box, refine_out ? (_Float16 *)c->ring_ref : nullptr, c->ring_cursor,
+                          (unsigned *)(c->ring_cursor + 1), c->ring_rows, B, 127 * 127};
+            ProfScope ps(c, st, "ring_commit", "ring_commit", 0.0, (double)B * (64.0 * 2 + (refine_out ? 127.0 * 127 * 6 : 0.0)));
+            if (launch_ring_commit(rg, st)) return fail(SMK_E_HIP, "ring_commit launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
         return 0;
     });
     if (rc) return rc;
     c->track_B = (flags & SMK_TRACK_MASK) ? B : 0;
+    return 0;
+}
+
+int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int rows) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    if (rows < 0 || (rows > 0 && !box_ring)) return fail(SMK_E_ARG, "smk_set_result_ring: rows %d / box ring %p", rows, (void *)box_ring);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    // the captured step graphs carry the ring pointers (or no commit launch at all): start over
+    for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
+    c->graphs.clear();
+    c->graph_used.clear();
+    c->graph_has_seq.clear();
+    if (!c->ring_cursor) HIPCHK(hipMalloc((void **)&c->ring_cursor, 2 * sizeof(int)));
+    HIPCHK(hipMemset(c->ring_cursor, 0, 2 * sizeof(int)));
+    c->ring_box = rows ? box_ring : nullptr;
+    c->ring_ref = rows ? refine_ring_f16 : nullptr;
+    c->ring_rows = rows;
+    return 0;
+}
+
+int smk_result_ring_cursor(smk_ctx *c, int *frames_out, int reset, void *stream) {
+    if (!c || !c->ring_cursor) return fail(SMK_E_STATE, "smk_result_ring_cursor: no result ring set");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (frames_out) HIPCHK(hipMemcpy(frames_out, c->ring_cursor, sizeof(int), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(c->ring_cursor, 0, 2 * sizeof(int)));
     return 0;
 }
 

@@ -569,6 +569,56 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
     decode_tail(p, a, b, rem, have, c0, c1, l0, l1, l2, l3);
 }
 
+// ---- result ring (smk_set_result_ring): what a tracker keeps per stream and frame for the end-of-batch gather --------------
+// (tools/test.py:296-311 keeps the box and the mask per frame; SURVEY.md 8e gathers them at the end of a batch of frames.)
+// One launch at the end of the frame step: the decoded box [B][8] f64 and the Refine logits [B][n] f32 -> f16 go to row
+// (cursor % rows) of the caller's rings, then the LAST workgroup to finish advances the cursor.  Every workgroup reads the
+// cursor before it can possibly have been advanced (the advance needs every workgroup's arrival), and the counter returns to
+// zero for the next graph replay.  16-byte loads, 8-byte stores; 0.8 MB at B = 8.
+__global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
+    __shared__ int row_sh;
+    if (threadIdx.x == 0) row_sh = __hip_atomic_load(p.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % p.rows;
+    __syncthreads();
+    const size_t row = (size_t)row_sh;
+    const size_t nref = (size_t)p.B * p.n;
+    if (p.ref_ring) {
+        _Float16 *dst = p.ref_ring + row * nref;
+        const bool vec = ((row * nref) & 3) == 0;                          // 8-byte stores need the row to start on one (B * n may be odd)
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nref; i += (size_t)gridDim.x * 256 * 4) {
+            if (vec && i + 4 <= nref) {
+                const float4 v = *(const float4 *)(p.ref + i);          // (B * n is odd in general: rows are not 16-byte multiples;
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));  //  i is a multiple of 4 from the base, both bases are 256-byte aligned)
+                h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *(h4 *)(dst + i) = o;
+            } else {
+                for (size_t j = i; j < i + 4 && j < nref; ++j) dst[j] = (_Float16)p.ref[j];
+            }
+        }
+    }
+    if (blockIdx.x == 0 && p.box_ring && threadIdx.x < p.B * 8) p.box_ring[row * p.B * 8 + threadIdx.x] = p.box[threadIdx.x];
+    __syncthreads();                                                      // every thread's stores are issued ...
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // ... and visible before the arrival
+        const unsigned prev = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.cursor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int launch_ring_commit(const RingParams &p, void *stream) {
+    if (!p.cursor || !p.done || p.rows < 1 || p.B < 1 || p.B * 8 > 256 * 4) return -1;
+    const size_t nref = (size_t)p.B * p.n;
+    int grid = (int)((nref + 256 * 4 * 2 - 1) / (256 * 4 * 2));           // two 16-byte loads per thread
+    if (grid < 1) grid = 1;
+    if (grid > 512) grid = 512;
+    RingParams q = p;
+    if (p.B * 8 > 256) return -1;
+    hipLaunchKernelGGL(ring_commit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 int launch_decode(const DecodeParams &p, void *stream) {
     if (p.A > 8 || p.B < 1 || p.S * p.S > DEC_THREADS || !p.part_val || !p.part_idx || !p.part_box || !p.arrived) return -1;
     hipLaunchKernelGGL(decode_kernel, dim3(p.A, p.B), dim3(DEC_THREADS), 0, (hipStream_t)stream, p);

@@ -273,6 +273,17 @@ struct DecodeParams {
     double penalty_k, window_influence;
 };
 
+// result ring (misc_kernels.hip ring_commit_kernel): row (cursor % rows) <- this frame's box + fp16 Refine logits; cursor advances
+struct RingParams {
+    const double *box;         // [B][8] f64 (smk_step's box_out)
+    const float *ref;          // [B][n] f32 (smk_step's refine_out) or nullptr
+    double *box_ring;          // [rows][B][8]
+    _Float16 *ref_ring;        // [rows][B][n] or nullptr
+    int *cursor;               // device: frames committed so far
+    unsigned *done;            // device: arrival counter of the launch's workgroups (zero between launches)
+    int rows, B, n;
+};
+
 // image ops either side of the network (image_kernels.hip); per-stream scalars travel in the kernarg
 constexpr int CROP_MAX_B = 32;
 struct CropParams {
@@ -348,6 +359,7 @@ int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
+int launch_ring_commit(const RingParams &p, void *stream);
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);
 int launch_paste_labels(const PasteParams &p, int n_obj, void *stream);

@@ -403,6 +403,8 @@ class Custom(nn.Module):
         B = search.shape[0]
         if refine is None:
             refine = self.variant == "sharp"
+        if getattr(self, "_ring", None) is not None and B != self._ring[2]:
+            raise ValueError("the result ring was set for batch %d, got %d" % (self._ring[2], B))
         if not stage:
             # serving fast path: everything about this call is cached per (input buffers, options)
             key = (search.data_ptr(), target_wh.data_ptr(), B, bool(refine), bool(mask_head))
@@ -450,6 +452,33 @@ class Custom(nn.Module):
                 self._fast.pop(next(iter(self._fast)))
             self._fast[key] = (args, out)
         return out
+
+    def set_result_ring(self, rows, batch=None, refine=True):
+        """Keep the last ``rows`` frames' results on the device (smk_set_result_ring): every track_step then also writes its
+        decoded box and its fp16 Refine logits into row (frames % rows) of the returned tensors
+        (box_ring [rows,B,8] float64, refine_ring [rows,B,16129] float16 or None) -- the rows an end-of-batch gather sends
+        (siammask_amd.dist.ResultGather), with no per-frame copy by the caller.  rows = 0 switches it off."""
+        if self._ctx is None:
+            raise RuntimeError("set_result_ring(): run template() first")
+        B = int(batch or (self.zf[1] if self.zf else self._max_batch))
+        dev = torch.device("cuda", self._ctx_device)
+        self._fast = {}
+        if rows <= 0:
+            _lib.check(_lib.lib().smk_set_result_ring(self._ctx, None, None, 0))
+            self._ring = None
+            return None, None
+        with torch.cuda.device(self._ctx_device):
+            box = torch.zeros((rows, B, 8), dtype=torch.float64, device=dev)
+            ref = torch.zeros((rows, B, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev) if refine else None
+        _lib.check(_lib.lib().smk_set_result_ring(self._ctx, box.data_ptr(), ref.data_ptr() if ref is not None else None, rows))
+        self._ring = (box, ref, B)
+        return box, ref
+
+    def result_ring_frames(self, reset=False):
+        """frames committed to the ring so far (synchronises the current stream)"""
+        n = ctypes.c_int(0)
+        _lib.check(_lib.lib().smk_result_ring_cursor(self._ctx, ctypes.byref(n), 1 if reset else 0, _lib.current_stream_ptr()))
+        return n.value
 
     def seq_status(self):
         """(workgroups per persistent sequence launch or 0, device error flag); raises if the kernel reported an error"""
