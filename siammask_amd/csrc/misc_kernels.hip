@@ -577,7 +577,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
 // zero for the next graph replay.  16-byte loads, 8-byte stores; 0.8 MB at B = 8.
 __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
     __shared__ int row_sh;
-    if (threadIdx.x == 0) row_sh = __hip_atomic_load(p.cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % p.rows;
+    if (threadIdx.x == 0) row_sh = *(volatile const int *)p.cursor % p.rows;      // (written by the previous step's launch: visible across the kernel boundary)
     __syncthreads();
     const size_t row = (size_t)row_sh;
     const size_t nref = (size_t)p.B * p.n;
@@ -595,10 +595,11 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
             }
         }
     }
-    if (blockIdx.x == 0 && p.box_ring && threadIdx.x < p.B * 8) p.box_ring[row * p.B * 8 + threadIdx.x] = p.box[threadIdx.x];
-    __syncthreads();                                                      // every thread's stores are issued ...
+    if (blockIdx.x == 0 && p.box_ring)
+        for (int i = threadIdx.x; i < p.B * 8; i += 256) p.box_ring[row * p.B * 8 + i] = p.box[i];
+    // (no release fence: the rows become visible to later kernels at the end of this launch like any other output; the counter
+    //  below only orders the cursor's advance behind every workgroup's READ of it, which happened at the top)
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // ... and visible before the arrival
         const unsigned prev = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {
             __hip_atomic_store(p.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -608,14 +609,12 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
 }
 
 int launch_ring_commit(const RingParams &p, void *stream) {
-    if (!p.cursor || !p.done || p.rows < 1 || p.B < 1 || p.B * 8 > 256 * 4) return -1;
+    if (!p.cursor || !p.done || p.rows < 1 || p.B < 1) return -1;
     const size_t nref = (size_t)p.B * p.n;
     int grid = (int)((nref + 256 * 4 * 2 - 1) / (256 * 4 * 2));           // two 16-byte loads per thread
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;
-    RingParams q = p;
-    if (p.B * 8 > 256) return -1;
-    hipLaunchKernelGGL(ring_commit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(ring_commit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
