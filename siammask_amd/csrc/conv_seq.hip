@@ -31,6 +31,7 @@ namespace smk {
 
 #include "wreg_tile.inc"
 #include "c3c1_tile.inc"
+#include "c3c1p_tile.inc"
 #include "wreg_halo_tile.inc"
 
 // weight ring depth (k-steps in flight per consumer wave) of the two patch-sharing tiles, and one (SB = 1) or two sets of activation
@@ -125,6 +126,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         const int cfg = L.cfg;
         // cfg 20 / 21: this layer (a Bottleneck's conv3) and the NEXT record (the 1x1 convolution that reads it: cfg 22) run as
         // ONE tile routine on 32-row tiles, no barrier in between (c3c1_tile.inc; the engine's seq_fuse_pairs marks the pairs)
+        const bool fusedp = cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2;      // ... the same pair split over two CUs (c3c1p_tile.inc)
         const bool fused = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2;
         // cfg 24 / 25: 3x3 stride-1 convolution on whole-row tiles (128 / 64 pixels x 64 channels) with the activation patch shared
         // by the nine taps (wreg_halo_tile.inc; the record's wgt_frag is the chunk-major fragment pack)
@@ -136,6 +138,30 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         const int halo_rpt = halo ? (cfg == SEQ_CFG_HALO128 ? 128 : 64) / L.Wo : 1;
         const int halo_tn = (L.Nst + 63) >> 6;
         const int tiles = fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
+        if (fusedp) {
+            // pair p = team slots 2p, 2p + 1; 64-row tiles dealt to the pairs (rows per tile evened out when one round covers the
+            // image: 961 rows -> 16 tiles of 61); each pair counts its exchanges in bar[8 + p]
+            const int npairs = nslots >> 1, pr = slot >> 1, hcu = slot & 1;
+            int rt = (hw + npairs - 1) / npairs;
+            if (rt > 64) rt = 64;
+            const int ptiles = (hw + rt - 1) / rt;
+            float *slabs = (float *)((unsigned char *)a.xch + (size_t)((team * SEQ_XCH_PAIRS + pr) * 4) * SEQ_XCH_SLAB);
+            for (int img = team; img < a.B && alive; img += 8)
+                for (int t = pr; t < ptiles && alive; t += npairs) {
+                    unsigned long long *tclk = nullptr;
+                    if constexpr (CLK != 0)
+                        tclk = (a.clk2 && team == 0 && slot == 0 && img == team && t == pr) ? a.clk2 + SEQ_CLK2_STRIDE * li : nullptr;
+                    const TeamWait w{&a, cnt, pending, &ctl[2]};
+                    pending = 0;
+                    const int fm0 = img * hw + t * rt;
+                    int fme = fm0 + rt;
+                    if (fme > (img + 1) * hw) fme = (img + 1) * hw;
+                    if (cfg == SEQ_CFG_C3C1P_L3)
+                        alive = c3c1p_tile<256, 1024, 256, CLK>(L, a.L[li + 1], fm0, fme, a.B * hw, hcu, pr, npairs, cnt + 8 + pr, slabs, a, &ctl[2], &ctl[3], smem, tclk, w);
+                    else
+                        alive = c3c1p_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, fme, a.B * hw, hcu, pr, npairs, cnt + 8 + pr, slabs, a, &ctl[2], &ctl[3], smem, tclk, w);
+                }
+        } else {
         const int nk = L.Kpad >> 6;
         // K-loop stagger: the workgroups of a team start at K tiles spread over the whole loop (L.kstag)
         const int kt0 = L.kstag ? (slot * nk) / nslots : 0;
@@ -189,9 +215,10 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
 #endif
                 else alive = wreg_tile<2, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
             }
+        }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (!alive) break;
-        if (fused) {                                     // the pair's second record: its time is in the first one's span
+        if (fused || fusedp) {                                     // the pair's second record: its time is in the first one's span
             if (clk) a.clk[2 + 2 * li] = a.clk[3 + 2 * li] = wall_clock64();
             ++li;
         }
@@ -216,6 +243,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
             __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int i = 8; i < 32; ++i) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // the pairs' exchange counters
         }
     }
 }
@@ -234,11 +262,16 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
     for (int li = 0; li < a.n; ++li) {
         const int cfg = a.L[li].cfg;
         a.L[li].bar_ord = 0;
-        if (cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2) {          // a pair: the second record must follow, its `sync` counts
+        const bool first = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2 || cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2;
+        if (first) {                                                     // a pair: the second record must follow, its `sync` counts
             if (li + 1 >= a.n || a.L[li + 1].cfg != SEQ_CFG_C3C1_2ND) return -1;
+            if ((cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2) && (!a.xch || (grid >> 3) % 2 || (grid >> 4) > SEQ_XCH_PAIRS)) return -1;
             continue;
         }
-        if (cfg == SEQ_CFG_C3C1_2ND && (li == 0 || (a.L[li - 1].cfg != SEQ_CFG_C3C1_L3 && a.L[li - 1].cfg != SEQ_CFG_C3C1_L2))) return -1;
+        if (cfg == SEQ_CFG_C3C1_2ND) {
+            const int pc = li ? a.L[li - 1].cfg : -1;
+            if (pc != SEQ_CFG_C3C1_L3 && pc != SEQ_CFG_C3C1_L2 && pc != SEQ_CFG_C3C1P_L3 && pc != SEQ_CFG_C3C1P_L2) return -1;
+        }
         if (a.L[li].sync && li + 1 < a.n) a.L[li].bar_ord = ++ord;
     }
     if (a.clk2)                                           // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)

@@ -250,6 +250,7 @@ struct smk_ctx {
     unsigned *ks_cnt = nullptr;
     // persistent per-XCD convolution sequences (conv_seq_kernel)
     unsigned *seq_bar = nullptr;     // [8][32] u32 team counters, zero between launches
+    float *seq_xch = nullptr;        // SEQ_XCH_BYTES: partial-sum slabs of the pair-split tiles (f16 contexts)
     int *seq_err = nullptr;          // device flag written by the kernel (placement / barrier timeout)
     int *seq_err_host = nullptr;     // the same flag in host-mapped pinned memory: read at every entry point without a sync
     int *seq_err_hdev = nullptr;     // device address of seq_err_host
@@ -589,6 +590,10 @@ static int build_arena(smk_ctx *c) {
     HIPCHK(hipMemset(c->seq_bar, 0, 8 * 32 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void **)&c->seq_err, sizeof(int)));
     HIPCHK(hipMemset(c->seq_err, 0, sizeof(int)));
+    if (c->dtype == DT_F16) {
+        HIPCHK(hipMalloc((void **)&c->seq_xch, SEQ_XCH_BYTES));
+        HIPCHK(hipMemset(c->seq_xch, 0, SEQ_XCH_BYTES));
+    }
     HIPCHK(hipHostMalloc((void **)&c->seq_err_host, 64, hipHostMallocMapped));
     *c->seq_err_host = 0;
     HIPCHK(hipHostGetDevicePointer((void **)&c->seq_err_hdev, c->seq_err_host, 0));
@@ -860,7 +865,7 @@ static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
     // caller chained independent members with sync = 0).  Whoever wrote the residual inside this list must be separated from
     // layer i by a barrier the workgroup has already PASSED, i.e. one behind a layer j' with writer <= j' < pend.
     // (The first record of an already marked pair carries no barrier of its own.)
-    auto has_bar = [&](int k) { return L[k].sync && L[k].cfg != SEQ_CFG_C3C1_L3 && L[k].cfg != SEQ_CFG_C3C1_L2; };
+    auto has_bar = [&](int k) { return L[k].sync && L[k].cfg != SEQ_CFG_C3C1_L3 && L[k].cfg != SEQ_CFG_C3C1_L2 && L[k].cfg != SEQ_CFG_C3C1P_L3 && L[k].cfg != SEQ_CFG_C3C1P_L2; };
     int pend = -1;
     for (int k = i - 1; k >= 0; --k)
         if (has_bar(k)) { pend = k; break; }
@@ -883,7 +888,7 @@ static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
     return true;
 }
 static int g_seq_fused_last = 0;          // pairs fused in the list that was launched last (smk_tune_get "seq_fused_last", a diagnostic)
-static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *locked = nullptr) {
+static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *locked = nullptr, bool have_xch = false) {
     g_seq_fused_last = 0;
     if (!g_tune.seq_fuse) return;
     for (int i = 0; i + 1 < n; ++i) {
@@ -897,6 +902,9 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
         const size_t px = (size_t)B * L[i].Ho * L[i].Wo;
         const size_t widest = std::max(std::max((size_t)L[i].Cs, (size_t)L[i].Cos), std::max((size_t)L[i].res_Cs, (size_t)L[i + 1].Cos));
         if (px * widest * 2 >= 0x7fff0000u || L[i].in_bytes >= 0x7fff0000u) continue;
+        // smk_tune "seq_pair2d": the pair split over two CUs (needs the exchange scratch: f16 contexts / smk_op_conv_seq have it)
+        if (have_xch && g_tune.seq_pair2d && (g_tune.seq_pair2d == 1 || code == SEQ_CFG_C3C1_L3))
+            code = code == SEQ_CFG_C3C1_L3 ? SEQ_CFG_C3C1P_L3 : SEQ_CFG_C3C1P_L2;
         L[i].cfg = (signed char)code;
         L[i + 1].cfg = (signed char)SEQ_CFG_C3C1_2ND;
         if (!(g_tune.seq_kstag_mask & 1)) L[i].kstag = 0;
@@ -917,6 +925,14 @@ static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids,
         const unsigned long long *t = h2 + 12 * i;
         if (!t[0] || !t[6]) continue;
         const double us = (t[6] - t[0]) / 100.0;
+        if (a.L[i].cfg == SEQ_CFG_C3C1P_L3 || a.L[i].cfg == SEQ_CFG_C3C1P_L2) {     // a pair split over two CUs: c3c1p_tile's phases
+            fprintf(stderr, "[seq clk2]  %-10s first tile (pair split, fused with the next 1x1): team wait %.2f | activation rows -> LDS %.2f | "
+                    "conv3 K loop %.2f | residual -> Y %.2f | Y = relu(..) %.2f | Y stores + second K loop + slab + arrive %.2f | partner wait + add %.2f | "
+                    "stores %.2f us | %.0f MHz\n",
+                    ids[i].c_str(), (t[7] - t[0]) / 100.0, (t[1] - t[7]) / 100.0, (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0,
+                    (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[10] - t[5]) / 100.0, (t[6] - t[10]) / 100.0, us > 0 ? (double)(t[9] - t[8]) / us : 0.0);
+            continue;
+        }
         if (a.L[i].cfg == SEQ_CFG_C3C1_L3 || a.L[i].cfg == SEQ_CFG_C3C1_L2) {       // a fused pair: c3c1_tile's phases
             fprintf(stderr, "[seq clk2]  %-10s first tile (fused with the next 1x1): team wait %.2f | activation rows -> LDS %.2f | "
                     "conv3 K loop %.2f | residual -> Y %.2f | Y = relu(..) %.2f | Y stores + second K loop %.2f | its epilogue + stores %.2f us | %.0f MHz\n",
@@ -940,10 +956,11 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.n = (int)(n - i0 < (size_t)SEQ_MAX ? n - i0 : SEQ_MAX);
         a.B = B;
         a.bar = c->seq_bar;
+        a.xch = c->seq_xch;
         a.err = c->seq_err;
         a.err_host = c->seq_err_hdev;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
-        seq_fuse_pairs(a.L, a.n, B);                     // (a pair never straddles two launches: it is marked inside one list)
+        seq_fuse_pairs(a.L, a.n, B, nullptr, c->seq_xch != nullptr && (c->seq_grid >> 3) % 2 == 0 && (c->seq_grid >> 4) <= SEQ_XCH_PAIRS);   // (a pair never straddles two launches)
         const char *ck = getenv("SMK_SEQ_CLK");
         const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
@@ -1725,6 +1742,7 @@ int smk_destroy(smk_ctx *c) {
     if (c->ks_part) hipFree(c->ks_part);
     if (c->ks_cnt) hipFree(c->ks_cnt);
     if (c->seq_bar) hipFree(c->seq_bar);
+    if (c->seq_xch) hipFree(c->seq_xch);
     if (c->seq_err) hipFree(c->seq_err);
     if (c->seq_err_host) hipHostFree(c->seq_err_host);
     if (c->seq_clk) hipFree(c->seq_clk);
@@ -1996,6 +2014,7 @@ int smk_tune(const char *key, int value) {
     }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
+    else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
     else if (!strcmp(key, "seq_halo")) g_tune.seq_halo = value != 0;
@@ -2044,7 +2063,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
@@ -2516,8 +2535,10 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     const char *ck = getenv("SMK_SEQ_CLK");
     const bool want2 = ck && !strcmp(ck, "2");
     if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
-    a.bar = bar; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
-    seq_fuse_pairs(a.L, a.n, B, &locked);                   // what the engine does with its own lists (smk_tune "seq_fuse")
+    float *xch = nullptr;
+    CHK(tmp.alloc((void **)&xch, SEQ_XCH_BYTES));
+    a.bar = bar; a.xch = xch; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
+    seq_fuse_pairs(a.L, a.n, B, &locked, (grid >> 3) % 2 == 0 && (grid >> 4) <= SEQ_XCH_PAIRS);                   // what the engine does with its own lists (smk_tune "seq_fuse")
     if (n_fused_out) {
         *n_fused_out = 0;
         for (int i = 0; i < n; ++i) *n_fused_out += a.L[i].cfg == SEQ_CFG_C3C1_2ND;

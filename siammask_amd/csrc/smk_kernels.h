@@ -114,6 +114,13 @@ static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
 constexpr int SEQ_CFG_C3C1_L3 = 20;    // K 256 -> N 1024 (+ residual, ReLU) -> N 256   (layer3 conv3 -> next conv1 / adjust)
 constexpr int SEQ_CFG_C3C1_L2 = 21;    // K 128 -> N 512  (+ residual, ReLU) -> N 128   (layer2 conv3 -> next conv1)
 constexpr int SEQ_CFG_C3C1_2ND = 22;   // the pair's second record
+// the same pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc): 64-row tiles, each CU half of conv3's channels and the
+// matching K half of the second convolution, fp32 partial sums exchanged through SeqArgs::xch; second record = 22 as well
+constexpr int SEQ_CFG_C3C1P_L3 = 26;
+constexpr int SEQ_CFG_C3C1P_L2 = 27;
+constexpr int SEQ_XCH_SLAB = 32768;    // bytes of one slab (c3c1p_tile.inc C3C1P_SLAB_MAX); a pair owns 2 sets x 2 destinations
+constexpr int SEQ_XCH_PAIRS = 16;      // pairs per team the scratch is sized for (32 workgroups per XCD)
+constexpr size_t SEQ_XCH_BYTES = (size_t)8 * SEQ_XCH_PAIRS * 4 * SEQ_XCH_SLAB;
 // 3x3 stride-1 (dilated) convolutions on whole-row tiles with the activation patch shared by the nine taps (wreg_halo_tile.inc);
 // the record's wgt_frag points at the chunk-major fragment pack (PackedConv::w_frag_halo)
 constexpr int SEQ_CFG_HALO128 = 24;    // 128 pixels (whole output rows) x 64 channels
@@ -121,7 +128,8 @@ constexpr int SEQ_CFG_HALO64 = 25;     // 64 pixels x 64 channels
 constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
-    unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits, [2] tickets
+    unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits, [2] tickets, [8 + p] exchanges of pair p
+    float *xch;            // SEQ_XCH_BYTES of scratch for the pair-split tiles' partial sums (nullptr: the list has none)
     int *err;              // device flag: 1 = an XCD received more workgroups than grid / 8, 2 = barrier timeout; a launch that
                            //   finds it set returns at once
     int *err_host;         // the same flag in host-mapped pinned memory (the engine checks it at every entry, no sync)
@@ -177,6 +185,9 @@ struct Tuning {
     int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
                                // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = every pair the routine has a
                                // shape for, 2 = layer3's pairs only (A/B knob), 3 = same as 1
+    int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
+                               // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
+                               // exchanged): 0 = c3c1_tile (one CU, 32 rows, all channels), 1 = every pair, 2 = layer3's pairs only
     int seq_halo = 1;          // sequences: 3x3 stride-1 layers with N <= 256 (the Bottlenecks' conv2) on whole-row tiles with the activation patch
                                // shared by the nine taps (wreg_halo_tile.inc); 0 = the im2col tiles of wreg_tile
     int seq_kstag_mask = 7;    // which tile routines of the sequences stagger their K loops: 1 = fused pairs, 2 = patch-sharing tiles, 4 = im2col tiles

@@ -215,6 +215,81 @@ def test_conv_seq_fused_conv3_conv1_pairs(shape, B, S):
         assert rel_err(outs[i].cpu().numpy(), plain[i].cpu().numpy().astype(np.float64)) <= 1e-3, i
 
 
+@pytest.mark.parametrize("shape", [(1024, 256), (512, 128)])
+@pytest.mark.parametrize("B,S", [(3, 23), (8, 31), (10, 15), (8, 47)])
+def test_conv_seq_pair_split_over_two_cus(shape, B, S):
+    """the same pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc, smk_tune seq_pair2d): 64-row tiles, each CU half of conv3's
+    channels and the matching K half of the second convolution, fp32 partial sums exchanged through the pair's slabs.  Ragged
+    tiles and idle pairs (23 x 23 = 529 rows -> 16 tiles of 34; B = 3: idle teams), the bench's shape (961 rows -> 16 tiles of 61),
+    two images on two of the teams (B = 10: consecutive exchanges of a pair, both slab sets), several rounds of tiles per pair
+    (47 x 47 = 2209 rows -> 35 tiles of 64 on 16 pairs: the last round has idle pairs).  Both outputs of the pair one layer deep;
+    against the one-CU routine: conv1 / conv2 bit-equal, the pair within summation-order noise; 5 launches bit-identical."""
+    from siammask_amd import _lib
+    ops = _ops()
+    cin, planes = shape
+    rng = np.random.default_rng(171 + cin + B + S)
+    x = rng.uniform(-1, 1, size=(B, cin, S, S)).astype(np.float32)
+    tail = _bottleneck(rng, planes, planes // 2, dil=1)
+    tail[2]["res"] = 3
+    layers = _two_blocks(rng, cin, planes) + tail
+    xd = torch.from_numpy(x).cuda()
+    info = {}
+    assert _lib.tune_get("seq_fuse") == 1
+    old = _lib.tune_get("seq_pair2d")
+    try:
+        _lib.tune(seq_pair2d=1)
+        outs, _, _ = ops.conv_seq(xd, layers, info=info)
+        assert info["fused_pairs"] == 1, info
+        again, _, _ = ops.conv_seq(xd, layers, iters=5, info=info)
+        _lib.tune(seq_pair2d=0)
+        one_cu, _, _ = ops.conv_seq(xd, layers, info=info)
+        assert info["fused_pairs"] == 1
+    finally:
+        _lib.tune(seq_pair2d=old)
+    _check(x, layers, outs, "pair split %s B=%d S=%d" % (shape, B, S))
+    for u, v in zip(outs, again):
+        assert torch.equal(u, v), "repeated launches of the pair-split list differ"
+    for i in (0, 1):
+        assert torch.equal(outs[i], one_cu[i]), i
+    for i in (2, 3):      # (the K-loop stagger starts a tile's k-steps elsewhere: another fp32 summation order, then fp16 rounding)
+        assert rel_err(outs[i].cpu().numpy(), one_cu[i].cpu().numpy().astype(np.float64)) <= 1e-3, i
+
+
+def test_conv_seq_pair_split_chain_of_layer3_blocks_and_adjust():
+    """three identity Bottlenecks of layer3 + adjust at the bench's batch with every pair split over two CUs: three exchanges per
+    pair and launch (slab sets 0, 1, 0), each pair's residual is the previous pair's conv3 output (written in two channel halves
+    by two CUs)"""
+    from siammask_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(181)
+    x = rng.uniform(-1, 1, size=(8, 1024, 31, 31)).astype(np.float32)
+    layers = []
+    for b in range(3):
+        blk = _bottleneck(rng, 1024, 256)
+        if b:
+            blk[0]["src"] = len(layers) - 1
+            blk[2]["res"] = len(layers) - 1
+        layers += blk
+    layers.append(dict(w=_w(rng, 256, 1024, 1), b=rng.uniform(-1, 1, 256).astype(np.float32), relu=False))
+    info = {}
+    xd = torch.from_numpy(x).cuda()
+    old = _lib.tune_get("seq_pair2d")
+    try:
+        _lib.tune(seq_pair2d=1)
+        outs, us, clk = ops.conv_seq(xd, layers, iters=5, info=info)
+        assert info["fused_pairs"] == 3, info
+        again, _, _ = ops.conv_seq(xd, layers, info=info)
+        _lib.tune(seq_pair2d=0)
+        _, us1, clk1 = ops.conv_seq(xd, layers, iters=5, info=info)
+    finally:
+        _lib.tune(seq_pair2d=old)
+    _check(x, layers, outs, "layer3 chain, pair split")
+    for u, v in zip(outs, again):
+        assert torch.equal(u, v)
+    print("layer3 chain: pair split %.1f us per launch (per layer %s) vs one CU per 32 rows %.1f us (%s)" % (
+        us, np.round(clk[:, 0], 1).tolist(), us1, np.round(clk1[:, 0], 1).tolist()))
+
+
 def test_conv_seq_fused_chain_of_layer3_blocks_and_adjust():
     """three identity Bottlenecks of layer3 + adjust at the bench's batch: conv1, conv2, [conv3 + conv1], conv2, [conv3 + conv1],
     conv2, [conv3 + adjust (no ReLU)] -- every fused pair's residual is the previous pair's conv3 output, written from LDS"""
