@@ -1540,7 +1540,9 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
             CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
         }
         Act V2 = act(c, "rf_s2", 15, 15, 32), V1 = act(c, "rf_s1", 31, 31, 16), V0 = act(c, "rf_s0", 61, 61, 8);
-        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3}, {"v1.2", &v1a, &V1, r3}, {"v0.2", &v0a, &V0, r3}}, B, 0, s));
+        ConvOpt r3l = r3;
+        r3l.tile_code = g_tune.rf_tile2;          // (A/B knob: workgroup tile of the merged v*.2 launch; 0 = the lead's own choice, 64x64)
+        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3}, {"v0.2", &v0a, &V0, r3}}, B, 0, s));
         static const char *ids[9] = {"h2.0", "h2.2", "post0", "h1.0", "h1.2", "post1", "h0.0", "h0.2", "post2"};
         static const int geo[9][3] = {{225, 32, 32}, {225, 32, 32}, {961, 32, 16}, {961, 16, 16}, {961, 16, 16},
                                       {3721, 16, 4}, {3721, 4, 4}, {3721, 4, 4}, {16129, 4, 1}};   // pixels, Cin, Cout
@@ -2040,6 +2042,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
+    else if (!strcmp(key, "rf_tile2")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "rf_tile2 0..5"); g_tune.rf_tile2 = value; }
     else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
@@ -2089,7 +2092,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
