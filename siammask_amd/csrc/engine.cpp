@@ -273,7 +273,10 @@ struct smk_ctx {
     double *ring_box = nullptr;
     void *ring_ref = nullptr;
     int ring_rows = 0;
-    int *ring_cursor = nullptr;      // device [2]: [0] frames committed, [1] arrival counter of ring_commit_kernel
+    int *ring_cursor = nullptr;      // device [2]: [0] frames committed, [1] arrival counter of the launch that advances it
+    bool ring_in_step = false;       // smk_step is recording: decode / the Refine chain take the ring writes with them
+    bool ring_step_refine = false;   // ... and a Refine launch follows the decode launch
+    bool ring_ref_folded = false;    // the chain launch took the fp16 logits + the cursor
 
     // decode (tools/test.py:205-254 on device)
     float anchor_w[8] = {104, 88, 64, 40, 32}, anchor_h[8] = {32, 40, 64, 80, 96};   // utils/anchors.py:40-50
@@ -1564,6 +1567,12 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         rp.out = out;
         rp.B = B;
         rp.clk = nullptr;
+        rp.ring = nullptr; rp.ring_cursor = nullptr; rp.ring_done = nullptr; rp.ring_rows = 0;
+        if (c->ring_in_step && c->ring_ref) {            // the frame's fp16 logits go to the result ring from post2 itself
+            rp.ring = (_Float16 *)c->ring_ref; rp.ring_cursor = c->ring_cursor; rp.ring_done = (unsigned *)(c->ring_cursor + 1);
+            rp.ring_rows = c->ring_rows;
+            c->ring_ref_folded = true;
+        }
         // SMK_CHAIN_CLK=1 (eager runs only): print the time workgroup 0 spends in each of the nine layers
         static const bool want_clk = getenv("SMK_CHAIN_CLK") != nullptr;
         static unsigned long long *clk_dev = nullptr;
@@ -2155,6 +2164,10 @@ static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, con
                       double *box_out, hipStream_t s) {
     DecodeParams p;
     fill_decode_params(c, cls, loc, B, target_wh, pos_out, box_out, p);
+    if (c->ring_in_step && c->ring_box && box_out) {     // result ring: the box goes to the ring from the decode launch itself
+        p.ring_box = c->ring_box; p.ring_cursor = c->ring_cursor; p.ring_done = (unsigned *)(c->ring_cursor + 1);
+        p.ring_rows = c->ring_rows; p.ring_advance = c->ring_step_refine ? 0 : 1;
+    }
     ProfScope ps(c, s, "decode", "decode", 0.0, (double)B * 30 * 625 * 4);
     if (launch_decode(p, s)) return fail(SMK_E_HIP, "decode launch failed");
     return 0;
@@ -2226,8 +2239,16 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
         int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, true);
         c->defer_mask_req = false;
         CHK(rc2);
-        CHK(seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st));
-        if (refine_out) CHK(seq_refine(c, B, refine_out, st));
+        // result ring (smk_set_result_ring): the decode launch writes the box row, the Refine chain launch the fp16 logits and
+        // advances the cursor; only a Refine that does NOT end in the chain kernel (fp32, smk_tune chain = 0) needs the
+        // stand-alone commit launch for its logits
+        c->ring_in_step = c->ring_rows > 0;
+        c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
+        c->ring_ref_folded = false;
+        int rcd = seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st);
+        if (!rcd && refine_out) rcd = seq_refine(c, B, refine_out, st);
+        c->ring_in_step = false;
+        CHK(rcd);
         if (c->have_deferred_mask) {                 // the chain launch did not take it (timing aid on, ...): its own launch
             c->have_deferred_mask = false;
             Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
@@ -2238,8 +2259,8 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
             c->mask_join_pending = false;
             CHK(stream_dep(c, c->side[0], st));
         }
-        if (c->ring_rows > 0) {                      // keep this frame's results for the end-of-batch gather (smk_set_result_ring)
-            RingParams rg{box_out, refine_out, c->ring_box, refine_out ? (_Float16 *)c->ring_ref : nullptr, c->ring_cursor,
+        if (c->ring_rows > 0 && refine_out && c->ring_ref && !c->ring_ref_folded) {      // (the box row was written by the decode launch)
+            RingParams rg{box_out, refine_out, nullptr, (_Float16 *)c->ring_ref, c->ring_cursor,
                           (unsigned *)(c->ring_cursor + 1), c->ring_rows, B, 127 * 127};
             ProfScope ps(c, st, "ring_commit", "ring_commit", 0.0, (double)B * (64.0 * 2 + (refine_out ? 127.0 * 127 * 6 : 0.0)));
             if (launch_ring_commit(rg, st)) return fail(SMK_E_HIP, "ring_commit launch failed: %s", hipGetErrorString(hipGetLastError()));

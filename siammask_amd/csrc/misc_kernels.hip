@@ -550,6 +550,22 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
         for (int q = 0; q < 8; ++q)
             o[q] = __longlong_as_double((long long)__hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
+    if (p.ring_box && p.box_out) {
+        // result ring: this frame's box also goes to the ring's current row (the cursor was advanced by the previous frame's
+        // last launch: a plain read).  Without a Refine launch behind it the last stream to get here advances the cursor --
+        // every other stream's writer has read it before its own arrival.
+        const int row = *(volatile const int *)p.ring_cursor % p.ring_rows;
+        double *r = p.ring_box + ((size_t)row * p.B + b) * 8;
+        const double *o = p.box_out + 8 * b;
+        for (int q = 0; q < 8; ++q) r[q] = o[q];
+        if (p.ring_advance) {
+            const unsigned prev = __hip_atomic_fetch_add(p.ring_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (unsigned)p.B - 1) {
+                __hip_atomic_store(p.ring_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p.ring_cursor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

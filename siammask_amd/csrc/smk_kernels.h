@@ -301,6 +301,12 @@ struct DecodeParams {
     int B, A, S, stride;
     float anchor_w[8], anchor_h[8];
     double penalty_k, window_influence;
+    // result ring (smk_set_result_ring), folded into this launch: the stream's final writer also stores the box into row
+    // (*ring_cursor % ring_rows); ring_advance: no Refine launch follows, the last stream's writer advances the cursor
+    double *ring_box;        // [rows][B][8] or nullptr
+    int *ring_cursor;
+    unsigned *ring_done;
+    int ring_rows, ring_advance;
 };
 
 // result ring (misc_kernels.hip ring_commit_kernel): row (cursor % rows) <- this frame's box + fp16 Refine logits; cursor advances
@@ -368,6 +374,12 @@ struct RefineChainParams {
     float *out;                           // [B][127*127] f32
     int B;
     unsigned long long *clk;              // optional [11]: 100 MHz timestamps of workgroup 0 at the layer boundaries
+    // result ring folded into the chain: post2 also stores fp16 logits into row (*ring_cursor % ring_rows); the last workgroup
+    // to finish advances the cursor (every workgroup reads it at its start, the advance needs every workgroup's arrival)
+    _Float16 *ring;                       // [rows][B][127*127] or nullptr
+    int *ring_cursor;
+    unsigned *ring_done;
+    int ring_rows;
 };
 int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch

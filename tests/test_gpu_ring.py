@@ -55,6 +55,34 @@ def test_ring_rows_are_the_frames_results(B, rows):
     assert float(box.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("dtype,ring_refine,step_refine", [("f32", True, True), ("f16", False, True), ("f16", True, False)])
+def test_ring_other_step_shapes(dtype, ring_refine, step_refine):
+    """the ring writes travel with other launches depending on the step: fp32's Refine does not end in the chain kernel (its
+    logits take the stand-alone commit launch), a boxes-only ring, and a step without Refine (the decode launch advances the
+    cursor itself) -- rows and frame count must come out the same"""
+    B, rows = 4, 3
+    m = _model(B, dtype)
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=330)).cuda()
+    xs = [torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=330 + 7 * i)).cuda() for i in range(4)]
+    twh = torch.tensor([[60.0, 80.0]] * B, dtype=torch.float64).cuda()
+    m.template(z)
+    want = []
+    for x in xs:
+        o = m.track_step(x, twh, refine=step_refine, stage=False)
+        want.append({k: o[k].clone() for k in ("box", "refine") if o[k] is not None})
+    torch.cuda.synchronize()
+    box, ref = m.set_result_ring(rows, batch=B, refine=ring_refine)
+    assert (ref is not None) == ring_refine
+    for i, x in enumerate(xs):
+        o = m.track_step(x, twh, refine=step_refine, stage=False)
+        torch.cuda.synchronize()
+        assert torch.equal(o["box"], want[i]["box"])
+        assert torch.equal(box[i % rows], want[i]["box"]), i
+        if ring_refine and step_refine:
+            assert torch.equal(ref[i % rows], want[i]["refine"].half()), i
+        assert m.result_ring_frames() == i + 1, (i, m.result_ring_frames())
+
+
 def test_ring_needs_its_batch():
     m = _model(8)
     z = torch.from_numpy(synth.smooth_image_batch(4, 127, stream0=310)).cuda()
