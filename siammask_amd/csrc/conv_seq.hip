@@ -248,6 +248,25 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
     }
 }
 
+// ---- the fused (conv3 + residual + ReLU, next 1x1) pair as its OWN launch (round 4): batches that do not run the persistent sequence
+// (B = 1 .. 4, 9 .. 11, 32, 64, ...) get the pair's benefit -- one launch and one pass over the 1024-channel trunk instead of two --
+// without teams: workgroup t owns rows [32 t, 32 t + 32) of the flattened batch (a 1x1 convolution does not care about image
+// borders), no barrier, no hoist; the tile routine is the sequence's, bit for bit.
+template <int K3, int N3, int N1>
+__global__ __launch_bounds__(512, 1) void conv_pair_kernel(const SeqLayer L3, const SeqLayer L1, const int M) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C3C1Lds<K3, N3, N1>::v];
+    const int m0 = (int)blockIdx.x * 32;
+    (void)c3c1_tile<K3, N3, N1, 0>(L3, L1, m0, M, M, (int)(blockIdx.x & 31), 32, smem, nullptr, NoHoist());
+}
+
+int launch_conv_pair(const SeqLayer &L3, const SeqLayer &L1, int code, int M, void *stream) {
+    if (M < 1 || (code != SEQ_CFG_C3C1_L3 && code != SEQ_CFG_C3C1_L2)) return -1;
+    const dim3 grid((M + 31) / 32), block(512);
+    if (code == SEQ_CFG_C3C1_L3) hipLaunchKernelGGL((conv_pair_kernel<256, 1024, 256>), grid, block, 0, (hipStream_t)stream, L3, L1, M);
+    else hipLaunchKernelGGL((conv_pair_kernel<128, 512, 128>), grid, block, 0, (hipStream_t)stream, L3, L1, M);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 // census: which XCD does block i run on?  (smk_create checks the i % 8 assumption once per context)
 __global__ void xcc_census_kernel(int *out) {
     unsigned xcc;

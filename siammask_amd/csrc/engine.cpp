@@ -1246,6 +1246,34 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
     return 0;
 }
 
+// A Bottleneck's conv3 (+ residual + ReLU) and the 1x1 convolution that reads its output as ONE launch (conv_pair_kernel: the
+// sequence's c3c1_tile per 32 rows of the flattened batch) -- for the batches that do not run the persistent sequence.
+// Returns 1 when the pair is not eligible (the caller then issues the two convolutions), 0 when it was launched.
+static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act &out3, const ConvOpt &o3, const char *id1,
+                         const Act &out1, const ConvOpt &o1, int B, hipStream_t s) {
+    if (c->dtype != DT_F16 || !g_tune.pair_launch || c->seq_on || parallel_ok(c) || (c->prof && !c->prof_merge)) return 1;
+    auto i3 = c->conv.find(id3), i1 = c->conv.find(id1);
+    if (i3 == c->conv.end() || i1 == c->conv.end() || o1.win || o1.ups || o1.pos) return 1;
+    ConvParams p3, p1;
+    if (conv_params(c, i3->second, in3, &out3, B, o3, p3) || conv_params(c, i1->second, out3, &out1, B, o1, p1)) return 1;
+    SeqLayer L[2];
+    if (!seq_layer_from(p3, c->dtype, L[0], -1) || !seq_layer_from(p1, c->dtype, L[1], -1)) return 1;
+    int code = 0;
+    if (!seq_pair_fusable(L, 0, &code)) return 1;
+    const size_t px = (size_t)p3.M;
+    const size_t widest = std::max(std::max((size_t)L[0].Cs, (size_t)L[0].Cos), std::max((size_t)L[0].res_Cs, (size_t)L[1].Cos));
+    if (px * widest * 2 >= 0x7fff0000u || L[0].in_bytes >= 0x7fff0000u) return 1;     // (the routine's out-of-range offset: see seq_fuse_pairs)
+    const size_t es = esize(c->dtype);
+    const double flop = 2.0 * p3.M * ((double)p3.N * p3.Ci + (double)p1.N * p1.Ci);
+    const double bytes = ((double)p3.M * (p3.Ci + 2.0 * p3.N + p1.N) + (double)p3.N * p3.Ci + (double)p1.N * p1.Ci) * es;
+    char kn[48];
+    snprintf(kn, sizeof(kn), "conv_pair<f16,%d-%d-%d>", p3.Ci, p3.N, p1.N);
+    const std::string pid = std::string(id3) + "+" + id1;
+    ProfScope ps(c, s, pid.c_str(), kn, flop, bytes);
+    if (launch_conv_pair(L[0], L[1], code, p3.M, s)) return fail(SMK_E_HIP, "launch of pair %s failed: %s", pid.c_str(), hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the network
 // ---------------------------------------------------------------------------------------------
@@ -1291,6 +1319,8 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
         ~SeqScope() { c->seq_on = false; c->seq_rec.clear(); c->seq_ids.clear(); c->seq_flop = c->seq_bytes = 0.0; }
     } seq_scope(c, false);
     const bool seq_ok = seq_wanted(c, B) && !parallel_ok(c);
+    bool c1_done = false;                     // the previous block's conv3 launch already computed this block's conv1 (run_conv_pair)
+    bool adjust_done = false;
     for (int st = 0; st < 3; ++st) {
         // layer1 stays on the per-launch kernels: short K and 63 tiles of 64 rows per image (two rounds for 32 workgroups)
         // made it 140 us inside the sequence against 96 us as launches (SMK_SEQ_CLK, profiles/r02_seq_ab.txt)
@@ -1367,9 +1397,10 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
                     CHK(run_conv_jobs(c, {{id_ds.c_str(), &cur, &r, od}, {id_c1.c_str(), &cur, &t1, o1}}, B, 0, s));
                 }
                 res = r;
-            } else {
+            } else if (!c1_done) {
                 CHK(run_conv(c, id_c1.c_str(), cur, &t1, B, o1, s));
             }
+            c1_done = false;
             CHK(run_conv(c, (id + "c2").c_str(), t1, &t2, B, o2, s));
             if (b == 0 && par) CHK(stream_dep(c, c->side[0], s));
             const bool last = b == STAGE_BLOCKS[st] - 1;
@@ -1378,7 +1409,27 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
             Act out = act(c, oname, so, so, planes * 4);
             if (last && st == 2) c->p3_buf = oname;
             ConvOpt o3; o3.relu = 1; o3.res = &res; o3.res_mode = RES_PRE_RELU;
-            CHK(run_conv(c, (id + "c3").c_str(), t2, &out, B, o3, s));
+            // outside the persistent sequence: conv3 and the NEXT 1x1 convolution (the following block's conv1, or adjust behind
+            // layer3 on the search branch) as one launch where the pair routine has the shape (layer2 / layer3 identity blocks)
+            int paired = 1;
+            if (!c->seq_on && st >= 1) {
+                if (!last) {
+                    char idn[32];
+                    snprintf(idn, sizeof(idn), "l%d.%d.c1", st + 1, b + 1);
+                    Act t1n = act(c, T1N[st], so, so, planes);
+                    ConvOpt o1n; o1n.relu = 1;
+                    paired = run_conv_pair(c, (id + "c3").c_str(), t2, out, o3, idn, t1n, o1n, B, s);
+                    if (paired < 0) return paired;
+                    if (paired == 0) c1_done = true;
+                } else if (st == 2 && so >= 20) {
+                    Act se = act(c, "search", so, so, 256);
+                    ConvOpt oa0;
+                    paired = run_conv_pair(c, (id + "c3").c_str(), t2, out, o3, "adjust", se, oa0, B, s);
+                    if (paired < 0) return paired;
+                    if (paired == 0) adjust_done = true;
+                }
+            }
+            if (paired == 1) CHK(run_conv(c, (id + "c3").c_str(), t2, &out, B, o3, s));
             cur = out;
             sp = so;
         }
@@ -1389,7 +1440,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
         Act zf = act(c, "zf", sp - 8, sp - 8, 256);
         oa.win = true; oa.Hl = oa.Wl = sp - 8; oa.org_y = oa.org_x = 4;
         CHK(run_conv(c, "adjust", cur, &zf, B, oa, s));
-    } else {
+    } else if (!adjust_done) {
         Act se = act(c, "search", sp, sp, 256);
         CHK(run_conv(c, "adjust", cur, &se, B, oa, s));
     }
@@ -2051,6 +2102,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
+    else if (!strcmp(key, "pair_launch")) g_tune.pair_launch = value != 0;
     else if (!strcmp(key, "rf_tile2")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "rf_tile2 0..5"); g_tune.rf_tile2 = value; }
     else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
@@ -2101,7 +2153,7 @@ int smk_tune_get(const char *key, int *value) {
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
-        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
+        {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"pair_launch", &g_tune.pair_launch}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},

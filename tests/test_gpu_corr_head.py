@@ -61,3 +61,42 @@ def test_corr_head_fusion_equals_the_three_launches(variant, B):
     # nothing outside the real channels / pixels was touched: the logits' shapes are the reference's
     assert tuple(fused["cls"].shape) == (B, 10, 25, 25) and tuple(fused["loc"].shape) == (B, 20, 25, 25)
     assert torch.isfinite(fused["cls"]).all() and torch.isfinite(fused["loc"]).all()
+
+
+def _backbone(B, knob):
+    from siammask_amd import _lib
+    old = _lib.tune_get("pair_launch")
+    try:
+        _lib.tune(pair_launch=knob)
+        m = _model("sharp", B)
+        z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=420)).cuda()
+        x = torch.from_numpy(synth.image_batch(B, 255, stream0=420)).cuda()
+        m.template(z)
+        zf = m.debug_tensor("zf").clone()
+        cls, loc, mask = m.track_mask(x)
+        out = {"zf": zf, "cls": cls.clone(), "loc": loc.clone()}
+        for n in ("p2", "p3", "search"):
+            out[n] = m.debug_tensor(n).clone()
+        m.profile(2)
+        m.track_mask(x)
+        kernels = [r["kernel"].split("<")[0] for r in m.profile_dump()]
+        m.profile(0)
+        torch.cuda.synchronize()
+        return out, kernels
+    finally:
+        _lib.tune(pair_launch=knob if False else old)
+
+
+@pytest.mark.parametrize("B", [1, 3, 10])
+def test_pair_launch_equals_two_launches(B):
+    """conv_pair_kernel (round 4): outside the persistent sequence (B = 1, 3, 10 here) every identity Bottleneck's conv3 + the next
+    1x1 convolution -- and layer3's last conv3 + adjust -- run as ONE launch (the sequence's c3c1_tile per 32 rows of the flattened
+    batch).  Against the two launches: p2 / p3 / search / zf and the logits within fp16 summation-order noise; 9 launches fewer on
+    the search branch (3 pairs in layer2, 5 + adjust in layer3)."""
+    fused, kf = _backbone(B, 1)
+    plain, kp = _backbone(B, 0)
+    assert kf.count("conv_pair") == 9, kf
+    assert "conv_pair" not in kp and len(kp) == len(kf) + 9, (len(kp), len(kf))
+    for k in ("p2", "p3", "search", "zf", "cls", "loc"):
+        e = rel_err(fused[k].cpu().numpy(), plain[k].cpu().numpy().astype(np.float64))
+        assert e <= 3e-3, "B=%d: %s differs from the two-launch path by %.2e" % (B, k, e)
