@@ -1252,6 +1252,11 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
 static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act &out3, const ConvOpt &o3, const char *id1,
                          const Act &out1, const ConvOpt &o1, int B, hipStream_t s) {
     if (c->dtype != DT_F16 || !g_tune.pair_launch || c->seq_on || parallel_ok(c) || (c->prof && !c->prof_merge)) return 1;
+    // Measured (profiles/r04h_pair_launch_ab.txt, whole step, one process per batch): B = 4 -1.0 %, B = 10 -7..9 %, B = 32 0,
+    // B = 64 +1.2 %, B = 1 +2 % -- at B = 1 31 workgroups each stream the full 1 MB of weights where the two launches spread the
+    // image over the chip; at B = 64 the chain's 32-row tiles stream more L2 bytes than the 128 x 256 tiles of the two launches.
+    // 1 = where it pays (3 <= B <= 31), 2 = always (tests, A/B)
+    if (g_tune.pair_launch == 1 && (B < 3 || B > 31)) return 1;
     auto i3 = c->conv.find(id3), i1 = c->conv.find(id1);
     if (i3 == c->conv.end() || i1 == c->conv.end() || o1.win || o1.ups || o1.pos) return 1;
     ConvParams p3, p1;
@@ -2102,7 +2107,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
-    else if (!strcmp(key, "pair_launch")) g_tune.pair_launch = value != 0;
+    else if (!strcmp(key, "pair_launch")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pair_launch 0..2"); g_tune.pair_launch = value; }
     else if (!strcmp(key, "rf_tile2")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "rf_tile2 0..5"); g_tune.rf_tile2 = value; }
     else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }

@@ -84,7 +84,7 @@ def _backbone(B, knob):
         torch.cuda.synchronize()
         return out, kernels
     finally:
-        _lib.tune(pair_launch=knob if False else old)
+        _lib.tune(pair_launch=old)
 
 
 @pytest.mark.parametrize("B", [1, 3, 10])
@@ -93,7 +93,7 @@ def test_pair_launch_equals_two_launches(B):
     1x1 convolution -- and layer3's last conv3 + adjust -- run as ONE launch (the sequence's c3c1_tile per 32 rows of the flattened
     batch).  Against the two launches: p2 / p3 / search / zf and the logits within fp16 summation-order noise; 9 launches fewer on
     the search branch (3 pairs in layer2, 5 + adjust in layer3)."""
-    fused, kf = _backbone(B, 1)
+    fused, kf = _backbone(B, 2)                  # (2 = at every batch; the default rule takes 3 <= B <= 31)
     plain, kp = _backbone(B, 0)
     assert kf.count("conv_pair") == 9, kf
     assert "conv_pair" not in kp and len(kp) == len(kf) + 9, (len(kp), len(kf))
