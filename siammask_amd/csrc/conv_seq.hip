@@ -32,6 +32,7 @@ namespace smk {
 #include "wreg_tile.inc"
 #include "c3c1_tile.inc"
 #include "c3c1p_tile.inc"
+#include "c3c1s_tile.inc"
 #include "wreg_halo_tile.inc"
 
 // weight ring depth (k-steps in flight per consumer wave) of the two patch-sharing tiles, and one (SB = 1) or two sets of activation
@@ -259,8 +260,21 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(const SeqLayer L3, co
     (void)c3c1_tile<K3, N3, N1, 0>(L3, L1, m0, M, M, (int)(blockIdx.x & 31), 32, smem, nullptr, NoHoist());
 }
 
-int launch_conv_pair(const SeqLayer &L3, const SeqLayer &L1, int code, int M, void *stream) {
-    if (M < 1 || (code != SEQ_CFG_C3C1_L3 && code != SEQ_CFG_C3C1_L2)) return -1;
+// ... and on 64-row tiles (c3c1s_tile.inc: conv3 in two channel halves, the full Y image in LDS): half the weight bytes per row
+template <int K3, int N3, int N1>
+__global__ __launch_bounds__(512, 1) void conv_pair64_kernel(const SeqLayer L3, const SeqLayer L1, const int M) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C3C1SLds<K3, N3, N1>::v];
+    c3c1s_tile<K3, N3, N1>(L3, L1, (int)blockIdx.x * 64, M, M, smem);
+}
+
+int launch_conv_pair(const SeqLayer &L3, const SeqLayer &L1, int code, int M, void *stream, int rows) {
+    if (M < 1 || (code != SEQ_CFG_C3C1_L3 && code != SEQ_CFG_C3C1_L2) || (rows != 32 && rows != 64)) return -1;
+    if (rows == 64) {
+        const dim3 grid64((M + 63) / 64), block64(512);
+        if (code == SEQ_CFG_C3C1_L3) hipLaunchKernelGGL((conv_pair64_kernel<256, 1024, 256>), grid64, block64, 0, (hipStream_t)stream, L3, L1, M);
+        else hipLaunchKernelGGL((conv_pair64_kernel<128, 512, 128>), grid64, block64, 0, (hipStream_t)stream, L3, L1, M);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     const dim3 grid((M + 31) / 32), block(512);
     if (code == SEQ_CFG_C3C1_L3) hipLaunchKernelGGL((conv_pair_kernel<256, 1024, 256>), grid, block, 0, (hipStream_t)stream, L3, L1, M);
     else hipLaunchKernelGGL((conv_pair_kernel<128, 512, 128>), grid, block, 0, (hipStream_t)stream, L3, L1, M);

@@ -1257,6 +1257,7 @@ static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act 
     // image over the chip; at B = 64 the chain's 32-row tiles stream more L2 bytes than the 128 x 256 tiles of the two launches.
     // 1 = where it pays (3 <= B <= 31), 2 = always (tests, A/B)
     if (g_tune.pair_launch == 1 && (B < 3 || B > 31)) return 1;
+    const int pair_rows = g_tune.pair_launch == 3 ? 64 : 32;
     auto i3 = c->conv.find(id3), i1 = c->conv.find(id1);
     if (i3 == c->conv.end() || i1 == c->conv.end() || o1.win || o1.ups || o1.pos) return 1;
     ConvParams p3, p1;
@@ -1273,9 +1274,10 @@ static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act 
     const double bytes = ((double)p3.M * (p3.Ci + 2.0 * p3.N + p1.N) + (double)p3.N * p3.Ci + (double)p1.N * p1.Ci) * es;
     char kn[48];
     snprintf(kn, sizeof(kn), "conv_pair<f16,%d-%d-%d>", p3.Ci, p3.N, p1.N);
+    (void)pair_rows;
     const std::string pid = std::string(id3) + "+" + id1;
     ProfScope ps(c, s, pid.c_str(), kn, flop, bytes);
-    if (launch_conv_pair(L[0], L[1], code, p3.M, s)) return fail(SMK_E_HIP, "launch of pair %s failed: %s", pid.c_str(), hipGetErrorString(hipGetLastError()));
+    if (launch_conv_pair(L[0], L[1], code, p3.M, s, pair_rows)) return fail(SMK_E_HIP, "launch of pair %s failed: %s", pid.c_str(), hipGetErrorString(hipGetLastError()));
     return 0;
 }
 
@@ -2107,7 +2109,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
     else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
     else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
-    else if (!strcmp(key, "pair_launch")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pair_launch 0..2"); g_tune.pair_launch = value; }
+    else if (!strcmp(key, "pair_launch")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "pair_launch 0..3"); g_tune.pair_launch = value; }
     else if (!strcmp(key, "rf_tile2")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "rf_tile2 0..5"); g_tune.rf_tile2 = value; }
     else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }

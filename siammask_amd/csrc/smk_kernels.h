@@ -187,7 +187,7 @@ struct Tuning {
                                // shape for, 2 = layer3's pairs only (A/B knob), 3 = same as 1
     int rf_tile2 = 0;          // A/B knob: tile code (tile_from_code) of Refine's merged v*.2 launch, 0 = auto
     int pair_launch = 1;       // fp16, batches outside the persistent sequence: a Bottleneck's conv3 + the next 1x1 convolution as ONE launch
-                               // (conv_pair_kernel = c3c1_tile per 32 rows of the flattened batch); 0 = two launches, 1 = for 3 <= B <= 31 (measured), 2 = always
+                               // (conv_pair_kernel = c3c1_tile per 32 rows of the flattened batch); 0 = two launches, 1 = where measured to pay, 2 = always on 32-row tiles, 3 = always on 64-row tiles (c3c1s_tile)
     int corr_head = 1;         // fp16: dw_xcorr + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); 0 = the three launches of rounds 1-3
     int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
                                // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
@@ -359,7 +359,8 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
 // a sequence of convolutions as one persistent launch of `grid` workgroups (one per CU, a multiple of 8)
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream);
 // ONE fused (conv3 + residual + ReLU, next 1x1) pair as its own launch over M = B * H * W rows (code: SEQ_CFG_C3C1_L3 / _L2)
-int launch_conv_pair(const SeqLayer &L3, const SeqLayer &L1, int code, int M, void *stream);
+// rows: 32 (c3c1_tile) or 64 (c3c1s_tile: half the weight bytes per row, for large batches)
+int launch_conv_pair(const SeqLayer &L3, const SeqLayer &L1, int code, int M, void *stream, int rows);
 // resident workgroups per CU the runtime promises for conv_seq_kernel (0: it cannot run; smk_create's gate)
 int conv_seq_occupancy();
 // XCD id of every block of a `grid`-block launch -> host array (synchronous; smk_create's placement check)

@@ -87,6 +87,18 @@ def _backbone(B, knob):
         _lib.tune(pair_launch=old)
 
 
+@pytest.mark.parametrize("B", [2, 9])
+def test_pair_launch_on_64_row_tiles_equals_two_launches(B):
+    """the 64-row form (c3c1s_tile: conv3 in two channel halves, the full Y image in LDS; smk_tune pair_launch = 3) against the two
+    launches: ragged last tiles (B x 961 and B x 225 rows are no multiples of 64), both shapes, adjust"""
+    fused, kf = _backbone(B, 3)
+    plain, kp = _backbone(B, 0)
+    assert kf.count("conv_pair") == 9, kf
+    for k in ("p2", "p3", "search", "zf", "cls", "loc"):
+        e = rel_err(fused[k].cpu().numpy(), plain[k].cpu().numpy().astype(np.float64))
+        assert e <= 3e-3, "B=%d: %s differs from the two-launch path by %.2e" % (B, k, e)
+
+
 @pytest.mark.parametrize("B", [1, 3, 10])
 def test_pair_launch_equals_two_launches(B):
     """conv_pair_kernel (round 4): outside the persistent sequence (B = 1, 3, 10 here) every identity Bottleneck's conv3 + the next
