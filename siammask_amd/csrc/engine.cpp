@@ -1252,12 +1252,14 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
 static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act &out3, const ConvOpt &o3, const char *id1,
                          const Act &out1, const ConvOpt &o1, int B, hipStream_t s) {
     if (c->dtype != DT_F16 || !g_tune.pair_launch || c->seq_on || parallel_ok(c) || (c->prof && !c->prof_merge)) return 1;
-    // Measured (profiles/r04h_pair_launch_ab.txt, whole step, one process per batch): B = 4 -1.0 %, B = 10 -7..9 %, B = 32 0,
-    // B = 64 +1.2 %, B = 1 +2 % -- at B = 1 31 workgroups each stream the full 1 MB of weights where the two launches spread the
-    // image over the chip; at B = 64 the chain's 32-row tiles stream more L2 bytes than the 128 x 256 tiles of the two launches.
-    // 1 = where it pays (3 <= B <= 31), 2 = always (tests, A/B)
-    if (g_tune.pair_launch == 1 && (B < 3 || B > 31)) return 1;
-    const int pair_rows = g_tune.pair_launch == 3 ? 64 : 32;
+    // Measured (profiles/r04h_pair_launch_ab.txt, r04i_pair64_ab.txt; whole step, one process per batch, off / on / off / on):
+    //   32-row tiles (c3c1_tile):  B = 1 +2 %, B = 4 -1.0 %, B = 10 -5..8 %, B = 32 0, B = 64 +1.2 %
+    //   64-row tiles (c3c1s_tile): B = 1 +7 %, B = 10 -10..11 %, B = 32 -5.0 %, B = 64 -5.2 %
+    // At B = 1 a pair is 31 (16) workgroups that each stream the full 1 MB of weights where the two launches spread the image over
+    // the chip; from ~150 tiles on the 64-row form wins everywhere (half the weight bytes per row, the trunk written once and
+    // never re-read).  1 = the rule (off for B <= 2, 32-row tiles for 3 <= B <= 8, 64-row tiles from B = 9), 2 / 3 = always 32 / 64 rows.
+    if (g_tune.pair_launch == 1 && B < 3) return 1;
+    const int pair_rows = g_tune.pair_launch == 3 ? 64 : (g_tune.pair_launch == 2 ? 32 : (B >= 9 ? 64 : 32));
     auto i3 = c->conv.find(id3), i1 = c->conv.find(id1);
     if (i3 == c->conv.end() || i1 == c->conv.end() || o1.win || o1.ups || o1.pos) return 1;
     ConvParams p3, p1;

@@ -187,7 +187,7 @@ struct Tuning {
                                // shape for, 2 = layer3's pairs only (A/B knob), 3 = same as 1
     int rf_tile2 = 0;          // A/B knob: tile code (tile_from_code) of Refine's merged v*.2 launch, 0 = auto
     int pair_launch = 1;       // fp16, batches outside the persistent sequence: a Bottleneck's conv3 + the next 1x1 convolution as ONE launch
-                               // (conv_pair_kernel = c3c1_tile per 32 rows of the flattened batch); 0 = two launches, 1 = where measured to pay, 2 = always on 32-row tiles, 3 = always on 64-row tiles (c3c1s_tile)
+                               // (conv_pair_kernel = c3c1_tile per 32 rows of the flattened batch); 0 = two launches, 1 = the measured rule (off for B <= 2, 32-row tiles to B = 8, 64-row tiles -- c3c1s_tile -- from B = 9), 2 / 3 = always 32 / 64 rows
     int corr_head = 1;         // fp16: dw_xcorr + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); 0 = the three launches of rounds 1-3
     int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
                                // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
