@@ -1201,7 +1201,11 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
         if (bm) ++n_halo;
         if (bm == 64 || (bm == 0 && cb.p[i].kh == 3)) split_for_halo = false;
     }
-    if ((c->prof && !c->prof_merge) || cb.n == 1 || !g_tune.merge || (split_for_halo && n_halo)) {   // per-layer attribution while profiling (mode 1)
+    // Merging is for launches whose members under-fill the chip.  At large batches every member is a full launch on its own and
+    // the merged launch only forces ONE kernel instantiation on all of them (the shortcut 3x3 beside conv1 on the LDS-staged
+    // 256x128 tile instead of the register-fed 128x256: B = 64 +5.1 % without merging, profiles/r04j_b64_merge_ab.txt).
+    const bool merge_ok = g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
+    if ((c->prof && !c->prof_merge) || cb.n == 1 || !merge_ok || (split_for_halo && n_halo)) {   // per-layer attribution while profiling (mode 1)
         for (auto &j : jobs) CHK(run_conv(c, j.id, *j.in, j.out, B, j.o, s));
         return 0;
     }
@@ -1584,7 +1588,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
     ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
     Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
-    const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge;
+    const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
     if (merged) {
         // the window convs only depend on the kept backbone features and pos: one launch with deconv
         w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
@@ -2096,7 +2100,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "min_blocks_x16")) g_tune.min_blocks_x16 = value;
     else if (!strcmp(key, "concurrency")) g_concurrency_default = value;
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
-    else if (!strcmp(key, "merge")) g_tune.merge = value != 0;
+    else if (!strcmp(key, "merge")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "merge 0..2"); g_tune.merge = value; }
+    else if (!strcmp(key, "merge_max_batch")) g_tune.merge_max_batch = value;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
@@ -2159,7 +2164,7 @@ int smk_tune_get(const char *key, int *value) {
     static const struct { const char *name; int *slot; } knobs[] = {
         {"seq_fused_last", &g_seq_fused_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
-        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge},
+        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"pair_launch", &g_tune.pair_launch}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},

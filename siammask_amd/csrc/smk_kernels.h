@@ -168,7 +168,9 @@ struct Tuning {
                                // a cross-stream graph edge makes hipGraphLaunch cost ~1 ms of host time)
     int chain_mask = 1;        // fused frame step, fp16: the mask head runs inside the Refine chain launch (chain_mask_kernel)
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
-    int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows)
+    int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows): 0 never, 1 up to
+                               // merge_max_batch streams (beyond it every member fills the chip by itself), 2 always
+    int merge_max_batch = 24;      // measured (profiles/r04k_merge_crossover_ab.txt): merging -5 % at B = 10, -1.5 % at B = 16, 0 at B = 24, +3.3 % at B = 32, +5.1 % at B = 64
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
