@@ -230,6 +230,9 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 if (!w()) break;
             }
             team_arrive(cnt);
+            if constexpr (CLK != 0) {                    // (measurement build: when did EVERY slot of team 0 arrive at this barrier?)
+                if (a.clk2 && team == 0 && threadIdx.x == 0) a.clk2[SEQ_CLK2_STRIDE * SEQ_MAX + li * 32 + slot] = wall_clock64();
+            }
             pending = (unsigned)a.L[li].bar_ord * (unsigned)nslots;
         }
         if (clk) a.clk[2 + 2 * li] = wall_clock64();

@@ -924,6 +924,23 @@ static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids,
         fprintf(stderr, "[seq clk]   %-10s cfg %d sync %d kstag %d  tiles %.2f us  arrive %.2f us\n", ids[i].c_str(), a.L[i].cfg,
                 a.L[i].sync, a.L[i].kstag, (h[1 + 2 * i] - h[2 * i]) / 100.0, (h[2 + 2 * i] - h[1 + 2 * i]) / 100.0);
     if (!h2) return;
+    // arrival of team 0's 32 workgroups at the barrier behind each layer (SMK_SEQ_CLK=2): how much of a team wait is SKEW (the last
+    // arrival against the others) and how much the barrier's own latency (last arrival -> slot 0 past its wait in the next layer)?
+    for (int i = 0; i < a.n; ++i) {
+        const unsigned long long *ar = h2 + 12 * SEQ_MAX + 32 * i;
+        unsigned long long mn = ~0ull, mx = 0;
+        int nz = 0;
+        double sum = 0.0;
+        for (int q = 0; q < 32; ++q)
+            if (ar[q]) { mn = std::min(mn, ar[q]); mx = std::max(mx, ar[q]); ++nz; }
+        if (nz < 2) continue;
+        for (int q = 0; q < 32; ++q)
+            if (ar[q]) sum += (double)(mx - ar[q]);
+        unsigned long long rel = 0;                      // slot 0 past the wait: stamp 7 of its first tile in the next record that has one
+        for (int j = i + 1; j < a.n && !rel; ++j) rel = h2[12 * j + 7];
+        fprintf(stderr, "[seq arrive] %-10s %2d workgroups: first -> last arrival %.2f us, mean wait for the last one %.2f us, last arrival -> slot 0 "
+                "released %.2f us\n", ids[i].c_str(), nz, (mx - mn) / 100.0, sum / nz / 100.0, rel > mx ? (rel - mx) / 100.0 : -1.0);
+    }
     for (int i = 0; i < a.n; ++i) {
         const unsigned long long *t = h2 + 12 * i;
         if (!t[0] || !t[6]) continue;
@@ -969,8 +986,8 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
         const bool want_clk2 = want_clk && !strcmp(ck, "2");
         if (want_clk && !c->seq_clk) HIPCHK(hipMalloc((void **)&c->seq_clk, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
-        if (want_clk2 && !c->seq_clk2) HIPCHK(hipMalloc((void **)&c->seq_clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
-        if (want_clk2) HIPCHK(hipMemsetAsync(c->seq_clk2, 0, sizeof(unsigned long long) * 12 * SEQ_MAX, s));
+        if (want_clk2 && !c->seq_clk2) HIPCHK(hipMalloc((void **)&c->seq_clk2, sizeof(unsigned long long) * (12 + 32) * SEQ_MAX));
+        if (want_clk2) HIPCHK(hipMemsetAsync(c->seq_clk2, 0, sizeof(unsigned long long) * (12 + 32) * SEQ_MAX, s));
         a.clk = want_clk ? c->seq_clk : nullptr;
         a.clk2 = want_clk2 ? c->seq_clk2 : nullptr;
         char idn[96];
@@ -1006,7 +1023,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
             return fail(SMK_E_HIP, "launch of %s failed: %s", idn, hipGetErrorString(hipGetLastError()));
         c->seq_pending = c->cap_has_seq = true;          // (smk_seq_sync_check: the flag is worth a look once this has drained)
         if (want_clk) {                                  // per-layer spans of (team 0, slot 0), eager mode only
-            unsigned long long h[2 * SEQ_MAX + 1], h2[12 * SEQ_MAX];
+            unsigned long long h[2 * SEQ_MAX + 1], h2[(12 + 32) * SEQ_MAX];
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipMemcpy(h, c->seq_clk, sizeof(h), hipMemcpyDeviceToHost));
             if (want_clk2) HIPCHK(hipMemcpy(h2, c->seq_clk2, sizeof(h2), hipMemcpyDeviceToHost));
@@ -2650,7 +2667,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     CHK(tmp.alloc((void **)&clk, sizeof(unsigned long long) * (2 * SEQ_MAX + 1)));
     const char *ck = getenv("SMK_SEQ_CLK");
     const bool want2 = ck && !strcmp(ck, "2");
-    if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * 12 * SEQ_MAX));
+    if (want2) CHK(tmp.alloc((void **)&clk2, sizeof(unsigned long long) * (12 + 32) * SEQ_MAX));
     float *xch = nullptr;
     CHK(tmp.alloc((void **)&xch, SEQ_XCH_BYTES));
     a.bar = bar; a.xch = xch; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
@@ -2676,7 +2693,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     HIPCHK(hipMemcpy(&e, err, sizeof(int), hipMemcpyDeviceToHost));
     if (e) return fail(SMK_E_HIP, "conv_seq_kernel reported %s", e == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out");
     {
-        unsigned long long h[2 * SEQ_MAX + 1], h2[12 * SEQ_MAX];
+        unsigned long long h[2 * SEQ_MAX + 1], h2[(12 + 32) * SEQ_MAX];
         HIPCHK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
         if (clk_us_out)
             for (int i = 0; i < n; ++i) {
