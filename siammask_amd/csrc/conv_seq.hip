@@ -61,6 +61,18 @@ __device__ __forceinline__ void team_arrive(unsigned *cnt) {
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // executes in the XCD's L2
 }
 
+// One read of a team counter.  spoll: through the SCALAR path (s_load_dword ... glc: misses the scalar cache, served by the XCD's L2,
+// where the arrivals' atomics execute) -- the poll then does not travel the CU's vector memory path, where the workgroup's own requests
+// issued in front of the wait are queued; otherwise a vector sc1 load.  SeqArgs::flags bit 0 (smk_tune "seq_spoll").
+__device__ __forceinline__ unsigned team_poll(const unsigned *cnt, bool spoll) {
+    if (spoll) {
+        unsigned v;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(cnt) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 load: L2-served
+}
+
 // WAIT, at wreg_tile's hoist point.  The consumer waves carry weight loads in flight there, so the workgroup meets at an
 // LDS-only barrier (__syncthreads() would drain vmcnt).
 struct TeamWait {
@@ -72,7 +84,7 @@ struct TeamWait {
         if (target == 0) return true;
         if (threadIdx.x == SEQ_POLL_TID) {
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // sc1 load: L2-served
+            while (team_poll(cnt, (a->flags & 1) != 0) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (wall_clock64() - t0 > 20000000ull) {               // 0.2 s at 100 MHz: never hang the GPU
                     seq_raise(*a, 2);

@@ -975,6 +975,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         memset(&a, 0, sizeof(a));
         a.n = (int)(n - i0 < (size_t)SEQ_MAX ? n - i0 : SEQ_MAX);
         a.B = B;
+        a.flags = g_tune.seq_spoll ? 1 : 0;
         a.bar = c->seq_bar;
         a.xch = c->seq_xch;
         a.err = c->seq_err;
@@ -2119,6 +2120,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "stages")) { if (value != 0 && (value < 2 || value > 4)) return fail(SMK_E_ARG, "stages 0|2|3|4"); g_tune.stages = value; }
     else if (!strcmp(key, "merge")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "merge 0..2"); g_tune.merge = value; }
     else if (!strcmp(key, "merge_max_batch")) g_tune.merge_max_batch = value;
+    else if (!strcmp(key, "seq_spoll")) g_tune.seq_spoll = value != 0;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
@@ -2181,7 +2183,7 @@ int smk_tune_get(const char *key, int *value) {
     static const struct { const char *name; int *slot; } knobs[] = {
         {"seq_fused_last", &g_seq_fused_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
-        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch},
+        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"pair_launch", &g_tune.pair_launch}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
@@ -2595,6 +2597,7 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     SeqArgs a;
     memset(&a, 0, sizeof(a));
     a.n = n; a.B = B;
+    a.flags = g_tune.seq_spoll ? 1 : 0;
     std::vector<std::string> ids;
     std::vector<char> locked(n, 0);
     for (int i = 0; i < n; ++i) {

@@ -128,6 +128,7 @@ constexpr int SEQ_CFG_HALO64 = 25;     // 64 pixels x 64 channels
 constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
+    int flags, pad_;       // flags bit 0: the team barrier polls through the scalar memory path (smk_tune "seq_spoll")
     unsigned *bar;         // [8 teams][32] u32, zero between launches: [0] barrier arrivals, [1] exits, [2] tickets, [8 + p] exchanges of pair p
     float *xch;            // SEQ_XCH_BYTES of scratch for the pair-split tiles' partial sums (nullptr: the list has none)
     int *err;              // device flag: 1 = an XCD received more workgroups than grid / 8, 2 = barrier timeout; a launch that
@@ -170,7 +171,8 @@ struct Tuning {
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows): 0 never, 1 up to
                                // merge_max_batch streams (beyond it every member fills the chip by itself), 2 always
-    int merge_max_batch = 24;      // measured (profiles/r04k_merge_crossover_ab.txt): merging -5 % at B = 10, -1.5 % at B = 16, 0 at B = 24, +3.3 % at B = 32, +5.1 % at B = 64
+    int merge_max_batch = 24;
+    int seq_spoll = 1;         // conv_seq_kernel's team barrier polls with s_load_dword glc (scalar path) instead of a vector sc1 load      // measured (profiles/r04k_merge_crossover_ab.txt): merging -5 % at B = 10, -1.5 % at B = 16, 0 at B = 24, +3.3 % at B = 32, +5.1 % at B = 64
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible
     int wreg_stages = 0;       // A-ring depth of conv_wreg_kernel: 0 auto (3), 3 or 4
