@@ -1610,6 +1610,8 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     if (merged) {
         // the window convs only depend on the kept backbone features and pos: one launch with deconv
         w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
+        // smk_tune "rf_wreg": bit 0 the four members on the register-fed kernel, bits 4..6 its tile code (0 = 3: 64x64; 6 = 128x64)
+        if (g_tune.rf_wreg & 1) w2.wreg = w1.wreg = w0.wreg = od.wreg = ((g_tune.rf_wreg >> 4) & 7) ? ((g_tune.rf_wreg >> 4) & 7) : 3;
         CHK(run_conv_jobs(c, {{"v2.0", &p2, &v2a, w2}, {"v1.0", &p1, &v1a, w1}, {"v0.0", &p0, &v0a, w0},
                               {"deconv", &corr, &d1, od}}, B, 0, s));
     } else {
@@ -1627,7 +1629,9 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         Act V2 = act(c, "rf_s2", 15, 15, 32), V1 = act(c, "rf_s1", 31, 31, 16), V0 = act(c, "rf_s0", 61, 61, 8);
         ConvOpt r3l = r3;
         r3l.tile_code = g_tune.rf_tile2;          // (A/B knob: workgroup tile of the merged v*.2 launch; 0 = the lead's own choice, 64x64)
-        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3}, {"v0.2", &v0a, &V0, r3}}, B, 0, s));
+        ConvOpt r3w = r3;
+        if ((g_tune.rf_wreg & 2) && merged) r3l.wreg = r3w.wreg = ((g_tune.rf_wreg >> 8) & 7) ? ((g_tune.rf_wreg >> 8) & 7) : 3;      // bit 1: the v*.2 launch, bits 8..10 its tile code
+        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3w}, {"v0.2", &v0a, &V0, r3w}}, B, 0, s));
         static const char *ids[9] = {"h2.0", "h2.2", "post0", "h1.0", "h1.2", "post1", "h0.0", "h0.2", "post2"};
         static const int geo[9][3] = {{225, 32, 32}, {225, 32, 32}, {961, 32, 16}, {961, 16, 16}, {961, 16, 16},
                                       {3721, 16, 4}, {3721, 4, 4}, {3721, 4, 4}, {16129, 4, 1}};   // pixels, Cin, Cout
@@ -2121,6 +2125,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "merge")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "merge 0..2"); g_tune.merge = value; }
     else if (!strcmp(key, "merge_max_batch")) g_tune.merge_max_batch = value;
     else if (!strcmp(key, "seq_spoll")) g_tune.seq_spoll = value != 0;
+    else if (!strcmp(key, "rf_wreg")) g_tune.rf_wreg = value;
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
@@ -2183,7 +2188,7 @@ int smk_tune_get(const char *key, int *value) {
     static const struct { const char *name; int *slot; } knobs[] = {
         {"seq_fused_last", &g_seq_fused_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
-        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll},
+        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll}, {"rf_wreg", &g_tune.rf_wreg},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"pair_launch", &g_tune.pair_launch}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},

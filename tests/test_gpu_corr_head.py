@@ -112,3 +112,38 @@ def test_pair_launch_equals_two_launches(B):
     for k in ("p2", "p3", "search", "zf", "cls", "loc"):
         e = rel_err(fused[k].cpu().numpy(), plain[k].cpu().numpy().astype(np.float64))
         assert e <= 3e-3, "B=%d: %s differs from the two-launch path by %.2e" % (B, k, e)
+
+
+def _refine(B, knob):
+    from siammask_amd import _lib
+    old = _lib.tune_get("rf_wreg")
+    try:
+        _lib.tune(rf_wreg=knob)
+        m = _model("sharp", B)
+        z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=410)).cuda()
+        x = torch.from_numpy(synth.image_batch(B, 255, stream0=410)).cuda()
+        m.template(z)
+        m.track_mask(x)
+        pos = [(6 * b) % 25 for b in range(B)]                  # 0 and 24 (windows over the image border) included
+        ref = m.track_refine([(p, 24 - p) for p in pos]).clone()
+        m.profile(2)
+        m.track_refine([(p, 24 - p) for p in pos])
+        kernels = [r["kernel"] for r in m.profile_dump()]
+        m.profile(0)
+        torch.cuda.synchronize()
+        return ref, kernels
+    finally:
+        _lib.tune(rf_wreg=old)
+
+
+@pytest.mark.parametrize("B", [1, 8, 13])
+def test_refine_front_on_the_register_fed_kernel(B):
+    """Refine's two merged front launches (v2.0 / v1.0 / v0.0 + deconv, then the three v*.2; /root/reference/experiments/siammask_sharp/
+    custom.py:102-118,133-152) run on conv_wreg_kernel's 64x64 tiles by default (smk_tune rf_wreg = 3: hundreds of short-K workgroups,
+    where the LDS-staged kernel's per-workgroup set-up is what costs).  Same K split, same fp32 order: the 127 x 127 logits must be
+    BIT-identical to the LDS-staged launches', windows at the image border included."""
+    new, kn = _refine(B, 3)
+    old, ko = _refine(B, 0)
+    assert sum("conv_wreg" in k and "merged" in k for k in kn) == 2, kn
+    assert sum("conv_igemm" in k and "merged" in k for k in ko) == 2, ko
+    assert torch.equal(new, old)
