@@ -102,10 +102,13 @@ struct TeamWait {
     }
 };
 
-template <int NPW, int CLK = 0>
+// T3 = 1: the instantiation that also carries the triple routine (c3c1_tile FRONT = 1), launched only for lists that hold a triple --
+// carrying it costs every other routine of the kernel (196 against 100 spilled SGPRs: +7 us on the B = 8 sequence, profiles/r04x_*)
+template <int NPW, int CLK = 0, int T3 = 0>
 __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<4, 3>::v];
-    static_assert(C3C1Lds<256, 1024, 256>::v <= WregLds<4, 3>::v && C3C1Lds<128, 512, 128>::v <= WregLds<4, 3>::v, "LDS of the fused conv3 + conv1 tile");
+    constexpr int SEQ_LDS = (!T3 || WregLds<4, 3>::v > C3C1Lds<256, 1024, 256>::vx) ? WregLds<4, 3>::v : C3C1Lds<256, 1024, 256>::vx;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SEQ_LDS];
+    static_assert(C3C1Lds<256, 1024, 256>::v <= WregLds<4, 3>::v && C3C1Lds<128, 512, 128>::vx <= SEQ_LDS && SEQ_LDS + 64 <= 160 * 1024, "LDS of the fused tiles");
     static_assert(NPW == 4, "c3c1_tile computes on all eight waves");
     __shared__ int ctl[4];                               // [0] slot, [1] error flag found at entry, [2] abort
     // team = the XCD this workgroup really runs on (HW_REG_XCC_ID; the dispatcher deals consecutive blocks round-robin
@@ -141,6 +144,9 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         // ONE tile routine on 32-row tiles, no barrier in between (c3c1_tile.inc; the engine's seq_fuse_pairs marks the pairs)
         const bool fusedp = cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2;      // ... the same pair split over two CUs (c3c1p_tile.inc)
         const bool fused = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2;
+        // cfg 28 / 29: this layer (a Bottleneck's 3x3 convolution), the NEXT record (its conv3: cfg 30) and the one behind it (the 1x1
+        // that reads conv3's output: cfg 22) run as ONE tile routine on image-row tiles (c3c1_tile.inc, FRONT = 1; seq_fuse_triples)
+        const bool fused3 = cfg == SEQ_CFG_C2C3C1_L3 || cfg == SEQ_CFG_C2C3C1_L2;
         // cfg 24 / 25: 3x3 stride-1 convolution on whole-row tiles (128 / 64 pixels x 64 channels) with the activation patch shared
         // by the nine taps (wreg_halo_tile.inc; the record's wgt_frag is the chunk-major fragment pack)
         const bool halo = cfg == SEQ_CFG_HALO128 || cfg == SEQ_CFG_HALO64;
@@ -150,7 +156,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         const int hw = L.Ho * L.Wo;
         const int halo_rpt = halo ? (cfg == SEQ_CFG_HALO128 ? 128 : 64) / L.Wo : 1;
         const int halo_tn = (L.Nst + 63) >> 6;
-        const int tiles = fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
+        const int tiles = fused3 ? L.Ho : fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
         if (fusedp) {
             // pair p = team slots 2p, 2p + 1; 64-row tiles dealt to the pairs (rows per tile evened out when one round covers the
             // image: 961 rows -> 16 tiles of 61); each pair counts its exchanges in bar[8 + p]
@@ -188,7 +194,14 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                     tclk = (a.clk2 && team == 0 && slot == 0 && img == team && t == slot) ? a.clk2 + SEQ_CLK2_STRIDE * li : nullptr;
                 const TeamWait w{&a, cnt, pending, &ctl[2]};
                 pending = 0;
-                if (fused) {
+                if constexpr (T3 != 0)
+                if (fused3) {
+                    const int fm0 = img * hw + t * L.Wo;
+                    if (cfg == SEQ_CFG_C2C3C1_L3) alive = c3c1_tile<256, 1024, 256, CLK, TeamWait, 1>(a.L[li + 1], a.L[li + 2], fm0, fm0 + L.Wo, a.B * hw, slot, nslots, smem, tclk, w, &L, img, t);
+                    else alive = c3c1_tile<128, 512, 128, CLK, TeamWait, 1>(a.L[li + 1], a.L[li + 2], fm0, fm0 + L.Wo, a.B * hw, slot, nslots, smem, tclk, w, &L, img, t);
+                }
+                if (T3 != 0 && fused3) {}
+                else if (fused) {
                     const int fm0 = img * hw + t * 32;
                     if (cfg == SEQ_CFG_C3C1_L3) alive = c3c1_tile<256, 1024, 256, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
                     else alive = c3c1_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, m_end, a.B * hw, slot, nslots, smem, tclk, w);
@@ -231,6 +244,10 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         }
         if (clk) a.clk[1 + 2 * li] = wall_clock64();
         if (!alive) break;
+        if (fused3) {                                              // the triple's second and third record: their time is in the first one's span
+            if (clk) a.clk[2 + 2 * li] = a.clk[3 + 2 * li] = a.clk[4 + 2 * li] = a.clk[5 + 2 * li] = wall_clock64();
+            li += 2;
+        }
         if (fused || fusedp) {                                     // the pair's second record: its time is in the first one's span
             if (clk) a.clk[2 + 2 * li] = a.clk[3 + 2 * li] = wall_clock64();
             ++li;
@@ -311,6 +328,17 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
         const int cfg = a.L[li].cfg;
         a.L[li].bar_ord = 0;
         const bool first = cfg == SEQ_CFG_C3C1_L3 || cfg == SEQ_CFG_C3C1_L2 || cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2;
+        if (cfg == SEQ_CFG_C2C3C1_L3 || cfg == SEQ_CFG_C2C3C1_L2) {      // a triple: conv3 (30) and the 1x1 (22) must follow; the 1x1's `sync` counts
+            if (li + 2 >= a.n) return -1;
+            if (a.L[li + 1].cfg != SEQ_CFG_C2C3C1_MID || a.L[li + 2].cfg != SEQ_CFG_C3C1_2ND) return -1;
+            if (a.L[li].Wo + 2 * a.L[li].dil > 35 || a.L[li].Wo > 32) return -1;
+            continue;
+        }
+        if (cfg == SEQ_CFG_C2C3C1_MID) {
+            const int pc = li ? a.L[li - 1].cfg : -1;
+            if (pc != SEQ_CFG_C2C3C1_L3 && pc != SEQ_CFG_C2C3C1_L2) return -1;
+            continue;
+        }
         if (first) {                                                     // a pair: the second record must follow, its `sync` counts
             if (li + 1 >= a.n || a.L[li + 1].cfg != SEQ_CFG_C3C1_2ND) return -1;
             if ((cfg == SEQ_CFG_C3C1P_L3 || cfg == SEQ_CFG_C3C1P_L2) && (!a.xch || (grid >> 3) % 2 || (grid >> 4) > SEQ_XCH_PAIRS)) return -1;
@@ -318,11 +346,16 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
         }
         if (cfg == SEQ_CFG_C3C1_2ND) {
             const int pc = li ? a.L[li - 1].cfg : -1;
-            if (pc != SEQ_CFG_C3C1_L3 && pc != SEQ_CFG_C3C1_L2 && pc != SEQ_CFG_C3C1P_L3 && pc != SEQ_CFG_C3C1P_L2) return -1;
+            if (pc != SEQ_CFG_C3C1_L3 && pc != SEQ_CFG_C3C1_L2 && pc != SEQ_CFG_C3C1P_L3 && pc != SEQ_CFG_C3C1P_L2 && pc != SEQ_CFG_C2C3C1_MID) return -1;
         }
         if (a.L[li].sync && li + 1 < a.n) a.L[li].bar_ord = ++ord;
     }
-    if (a.clk2)                                           // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
+    bool triples = false;
+    for (int li = 0; li < a.n; ++li) triples = triples || a.L[li].cfg == SEQ_CFG_C2C3C1_L3 || a.L[li].cfg == SEQ_CFG_C2C3C1_L2;
+    if (triples) {
+        if (a.clk2) hipLaunchKernelGGL((conv_seq_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_seq_kernel<4, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    } else if (a.clk2)                                    // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
         hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_seq_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;

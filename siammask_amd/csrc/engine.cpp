@@ -266,6 +266,7 @@ struct smk_ctx {
     ConvParams deferred_mask;
     double deferred_mask_flop = 0.0, deferred_mask_bytes = 0.0;
     std::vector<SeqLayer> seq_rec;
+    std::vector<const void *> seq_wstd;      // per record: the (kh, kw, cin)-ordered fragment pack (seq_fuse_triples needs it where the record carries the chunk-major one)
     std::vector<std::string> seq_ids;
     double seq_flop = 0.0, seq_bytes = 0.0;
 
@@ -916,6 +917,71 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
     }
 }
 
+// Triples (round 4): [conv2 (3x3, stride 1, pad = dilation), conv3, the next 1x1] of a Bottleneck as ONE tile routine on image-row
+// tiles (c3c1_tile.inc, FRONT = 1).  Runs behind seq_fuse_pairs: a marked pair (i + 1, i + 2) whose first record reads what record i --
+// the block's 3x3 convolution -- writes, and nobody else reads it.  The barrier between conv2 and the pair disappears with the
+// tensor.  wstd[i] = the (kh, kw, cin)-ordered fragment pack of record i (the record itself carries the chunk-major pack of the
+// patch-sharing tile).  smk_tune "seq_fuse3": 0 off, 1 on, 2 layer3's blocks only.
+static int g_seq_fused3_last = 0;
+static void seq_fuse_triples(SeqLayer *L, int n, int B, const void *const *wstd, const std::vector<char> *locked = nullptr) {
+    g_seq_fused3_last = 0;
+    if (!g_tune.seq_fuse3 || !wstd) return;
+    auto group_has_bar = [&](int k) {            // a barrier stands behind record k (pairs / triples: behind their LAST record only)
+        const int cf = L[k].cfg;
+        if (cf == SEQ_CFG_C3C1_L3 || cf == SEQ_CFG_C3C1_L2 || cf == SEQ_CFG_C3C1P_L3 || cf == SEQ_CFG_C3C1P_L2 || cf == SEQ_CFG_C2C3C1_L3 ||
+            cf == SEQ_CFG_C2C3C1_L2 || cf == SEQ_CFG_C2C3C1_MID)
+            return false;
+        return L[k].sync != 0;
+    };
+    for (int i = 0; i + 2 < n; ++i) {
+        SeqLayer &c2 = L[i], &c3 = L[i + 1], &c1 = L[i + 2];
+        if (locked && ((*locked)[i] || (*locked)[i + 1] || (*locked)[i + 2])) continue;
+        if ((c3.cfg != SEQ_CFG_C3C1_L3 && c3.cfg != SEQ_CFG_C3C1_L2) || c1.cfg != SEQ_CFG_C3C1_2ND) continue;
+        if (c2.cfg != SEQ_CFG_HALO128 && c2.cfg != SEQ_CFG_HALO64 && c2.cfg > 9) continue;     // (a plain tile or the patch-sharing one)
+        const int code = c3.cfg == SEQ_CFG_C3C1_L3 ? SEQ_CFG_C2C3C1_L3 : SEQ_CFG_C2C3C1_L2;
+        if (g_tune.seq_fuse3 == 2 && code != SEQ_CFG_C2C3C1_L3) continue;
+        const int kc = c3.Kpad;                  // 256 / 128: conv2 is kc -> kc
+        if (c2.kh != 3 || c2.kw != 3 || c2.stride != 1 || c2.stride_x != 1 || c2.pad != c2.dil || c2.dil < 1 || c2.dil > 2) continue;
+        if (c2.Ci != kc || c2.Nst != kc || c2.Kpad != 9 * kc || !c2.relu || c2.res || c2.res_mode != RES_NONE || !c2.sync) continue;
+        if (c2.org_y || c2.org_x || c2.Hl != c2.Hs || c2.Wl != c2.Ws || c2.Ho != c2.Hs || c2.Wo != c2.Ws) continue;
+        if (c2.Wo > 32 || c2.Wo < 24 || c2.Wo + 2 * c2.dil > 35) continue;      // one image row per 32-row tile; short rows (the template's 15 x 15) stay pairs
+        if (c3.in != c2.out || c3.cin_off != c2.cout_off || c3.Cs != c2.Cos || c3.Hs != c2.Ho || c3.Ws != c2.Wo) continue;
+        if (!wstd[i]) continue;
+        bool other_reader = false;               // conv2's output never reaches memory: nobody else may read it ...
+        for (int j = i + 2; j < n; ++j) {        // ... until a later record writes that buffer again (the blocks of a layer share their intermediates)
+            if (L[j].in == c2.out || L[j].res == c2.out) { other_reader = true; break; }
+            if (L[j].out == c2.out) break;
+        }
+        if (other_reader || c2.out == c3.res || c2.out == c1.out || c2.out == c3.out) continue;
+        // conv2's input must have been written in front of the barrier this routine waits for (the last one before record i)
+        int pend = -1;
+        for (int k = i - 1; k >= 0; --k)
+            if (group_has_bar(k)) { pend = k; break; }
+        bool in_ok = true;
+        for (int j = i - 1; j >= 0; --j)
+            if (L[j].out == c2.in) { in_ok = j <= pend; break; }
+        if (!in_ok) continue;
+        // the residual rows: in front of the wait when their writer is separated from record i by a barrier ALREADY passed, or when it
+        // is the previous triple's conv3 on the same row tiles (then this very workgroup wrote them); behind the wait otherwise
+        int res_late = 0;
+        for (int j = i - 1; j >= 0; --j)
+            if (L[j].out == c3.res) {
+                bool passed = false;
+                for (int k = j; k < pend; ++k) passed = passed || group_has_bar(k);
+                const bool own_rows = L[j].cfg == SEQ_CFG_C2C3C1_MID && L[j].Ho == c3.Ho && L[j].Wo == c3.Wo;
+                if (!passed && !own_rows) res_late = 1;
+                break;
+            }
+        c2.cfg = (signed char)code;
+        c2.wgt_frag = wstd[i];
+        c2.sync = 0;
+        c3.cfg = (signed char)SEQ_CFG_C2C3C1_MID;
+        c3.a_stage = (signed char)res_late;
+        ++g_seq_fused3_last;
+        i += 2;
+    }
+}
+
 // SMK_SEQ_CLK (measurement aid, eager runs only): print what (team 0, slot 0) stamped
 static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids, const char *idn, const unsigned long long *h,
                           const unsigned long long *h2) {
@@ -953,6 +1019,13 @@ static void seq_print_clk(const SeqArgs &a, const std::vector<std::string> &ids,
                     (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[10] - t[5]) / 100.0, (t[6] - t[10]) / 100.0, us > 0 ? (double)(t[9] - t[8]) / us : 0.0);
             continue;
         }
+        if (a.L[i].cfg == SEQ_CFG_C2C3C1_L3 || a.L[i].cfg == SEQ_CFG_C2C3C1_L2) {   // a triple: c3c1_tile's phases with conv2 in front
+            fprintf(stderr, "[seq clk2]  %-10s first tile (3x3 + conv3 + the next 1x1): prologue + team wait %.2f | patch -> LDS + conv2 %.2f | "
+                    "conv3 K loop %.2f | residual -> Y %.2f | Y = relu(..) %.2f | Y stores + second K loop %.2f | its epilogue + stores %.2f us | %.0f MHz\n",
+                    ids[i].c_str(), (t[7] - t[0]) / 100.0, (t[1] - t[7]) / 100.0, (t[2] - t[1]) / 100.0, (t[3] - t[2]) / 100.0,
+                    (t[4] - t[3]) / 100.0, (t[5] - t[4]) / 100.0, (t[6] - t[5]) / 100.0, us > 0 ? (double)(t[9] - t[8]) / us : 0.0);
+            continue;
+        }
         if (a.L[i].cfg == SEQ_CFG_C3C1_L3 || a.L[i].cfg == SEQ_CFG_C3C1_L2) {       // a fused pair: c3c1_tile's phases
             fprintf(stderr, "[seq clk2]  %-10s first tile (fused with the next 1x1): team wait %.2f | activation rows -> LDS %.2f | "
                     "conv3 K loop %.2f | residual -> Y %.2f | Y = relu(..) %.2f | Y stores + second K loop %.2f | its epilogue + stores %.2f us | %.0f MHz\n",
@@ -982,6 +1055,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.err_host = c->seq_err_hdev;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
         seq_fuse_pairs(a.L, a.n, B, nullptr, c->seq_xch != nullptr && (c->seq_grid >> 3) % 2 == 0 && (c->seq_grid >> 4) <= SEQ_XCH_PAIRS);   // (a pair never straddles two launches)
+        seq_fuse_triples(a.L, a.n, B, c->seq_wstd.data() + i0);
         const char *ck = getenv("SMK_SEQ_CLK");
         const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
@@ -1033,6 +1107,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         }
     }
     c->seq_rec.clear();
+    c->seq_wstd.clear();
     c->seq_ids.clear();
     c->seq_flop = c->seq_bytes = 0.0;
     return 0;
@@ -1145,6 +1220,7 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
         SeqLayer L;
         if (!o.algo_naive && !o.halo && !o.wreg && !o.tile_code && seq_layer_from(p, c->dtype, L)) {
             c->seq_rec.push_back(L);
+            c->seq_wstd.push_back(p.wgt_frag);
             c->seq_ids.push_back(id);
             c->seq_flop += flop;
             c->seq_bytes += bytes;
@@ -1347,7 +1423,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
     struct SeqScope {
         smk_ctx *c;
         SeqScope(smk_ctx *c_, bool on) : c(c_) { c->seq_on = on; }
-        ~SeqScope() { c->seq_on = false; c->seq_rec.clear(); c->seq_ids.clear(); c->seq_flop = c->seq_bytes = 0.0; }
+        ~SeqScope() { c->seq_on = false; c->seq_rec.clear(); c->seq_wstd.clear(); c->seq_ids.clear(); c->seq_flop = c->seq_bytes = 0.0; }
     } seq_scope(c, false);
     const bool seq_ok = seq_wanted(c, B) && !parallel_ok(c);
     bool c1_done = false;                     // the previous block's conv3 launch already computed this block's conv1 (run_conv_pair)
@@ -2126,6 +2202,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "merge_max_batch")) g_tune.merge_max_batch = value;
     else if (!strcmp(key, "seq_spoll")) g_tune.seq_spoll = value != 0;
     else if (!strcmp(key, "rf_wreg")) g_tune.rf_wreg = value;
+    else if (!strcmp(key, "seq_fuse3")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_fuse3 0..2"); g_tune.seq_fuse3 = value; }
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
@@ -2188,7 +2265,7 @@ int smk_tune_get(const char *key, int *value) {
     static const struct { const char *name; int *slot; } knobs[] = {
         {"seq_fused_last", &g_seq_fused_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
-        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll}, {"rf_wreg", &g_tune.rf_wreg},
+        {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll}, {"rf_wreg", &g_tune.rf_wreg}, {"seq_fuse3", &g_tune.seq_fuse3}, {"seq_fused3_last", &g_seq_fused3_last},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
         {"seq", &g_tune.seq}, {"ablate", &g_tune.ablate}, {"seq_tall", &g_tune.seq_tall}, {"seq_kstag", &g_tune.seq_kstag},
         {"seq_deep", &g_tune.seq_deep}, {"seq_fuse", &g_tune.seq_fuse}, {"seq_pair2d", &g_tune.seq_pair2d}, {"corr_head", &g_tune.corr_head}, {"pair_launch", &g_tune.pair_launch}, {"rf_tile2", &g_tune.rf_tile2}, {"seq_ds128", &g_tune.seq_ds128}, {"seq_halo", &g_tune.seq_halo}, {"seq_kstag_mask", &g_tune.seq_kstag_mask}, {"res_nt", &g_tune.res_nt},
@@ -2680,6 +2757,11 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     CHK(tmp.alloc((void **)&xch, SEQ_XCH_BYTES));
     a.bar = bar; a.xch = xch; a.err = err; a.err_host = nullptr; a.clk = clk; a.clk2 = clk2;
     seq_fuse_pairs(a.L, a.n, B, &locked, (grid >> 3) % 2 == 0 && (grid >> 4) <= SEQ_XCH_PAIRS);                   // what the engine does with its own lists (smk_tune "seq_fuse")
+    {
+        std::vector<const void *> wstd(n);
+        for (int i = 0; i < n; ++i) wstd[i] = packs[i].w_frag;
+        seq_fuse_triples(a.L, a.n, B, wstd.data(), &locked);
+    }
     if (n_fused_out) {
         *n_fused_out = 0;
         for (int i = 0; i < n; ++i) *n_fused_out += a.L[i].cfg == SEQ_CFG_C3C1_2ND;

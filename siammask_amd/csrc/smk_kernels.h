@@ -118,6 +118,11 @@ constexpr int SEQ_CFG_C3C1_2ND = 22;   // the pair's second record
 // matching K half of the second convolution, fp32 partial sums exchanged through SeqArgs::xch; second record = 22 as well
 constexpr int SEQ_CFG_C3C1P_L3 = 26;
 constexpr int SEQ_CFG_C3C1P_L2 = 27;
+// triples (c3c1_tile.inc FRONT = 1; engine.cpp seq_fuse_triples): a Bottleneck's 3x3 convolution, its conv3 and the next 1x1 as ONE tile
+// routine on image-row tiles; records: conv2 = 28 / 29, conv3 = 30, the 1x1 = 22
+constexpr int SEQ_CFG_C2C3C1_L3 = 28;  // 3x3 256 -> 256, then the layer3 pair
+constexpr int SEQ_CFG_C2C3C1_L2 = 29;  // 3x3 128 -> 128, then the layer2 pair
+constexpr int SEQ_CFG_C2C3C1_MID = 30; // the triple's conv3 record (a_stage = 1: residual rows requested behind the team wait)
 constexpr int SEQ_XCH_SLAB = 32768;    // bytes of one slab (c3c1p_tile.inc C3C1P_SLAB_MAX); a pair owns 2 sets x 2 destinations
 constexpr int SEQ_XCH_PAIRS = 16;      // pairs per team the scratch is sized for (32 workgroups per XCD)
 constexpr size_t SEQ_XCH_BYTES = (size_t)8 * SEQ_XCH_PAIRS * 4 * SEQ_XCH_SLAB;
@@ -173,6 +178,7 @@ struct Tuning {
                                // merge_max_batch streams (beyond it every member fills the chip by itself), 2 always
     int merge_max_batch = 24;
     int rf_wreg = 3;           // Refine's two merged front launches on the register-fed kernel's 64x64 tile: bit 0 the window convolutions + deconv, bit 1 the v*.2 launch
+    int seq_fuse3 = 0;         // conv_seq_kernel: [conv2, conv3, next 1x1] of a Bottleneck as one tile routine on image-row tiles (0 off, 1 on, 2 layer3 only)
     int seq_spoll = 1;         // conv_seq_kernel's team barrier polls with s_load_dword glc (scalar path) instead of a vector sc1 load      // measured (profiles/r04k_merge_crossover_ab.txt): merging -5 % at B = 10, -1.5 % at B = 16, 0 at B = 24, +3.3 % at B = 32, +5.1 % at B = 64
     int wreg = 1;              // fp16 NHWC convolutions through conv_wreg_kernel (weights global -> VGPR, activations
                                // through LDS): 0 off, 1 per-shape choice (wreg_choice), 2..7 force tile code 1..6 where eligible

@@ -509,3 +509,76 @@ def test_side_stream_work_during_a_step_stays_correct_or_raises():
         raised += _safe_step(m, z, x, twh, want, "side stream, round %d" % it)
     torch.cuda.synchronize()
     print("side stream: failure path taken %d times of 4" % raised)
+
+
+def _chain(rng, cin, planes, nblocks, dil, adjust=True):
+    layers = []
+    for b in range(nblocks):
+        blk = _bottleneck(rng, cin, planes, dil=dil)
+        if b:
+            blk[0]["src"] = len(layers) - 1
+            blk[2]["res"] = len(layers) - 1
+        layers += blk
+    layers.append(dict(w=_w(rng, planes, cin, 1), b=rng.uniform(-1, 1, planes).astype(np.float32), relu=not adjust))
+    return layers
+
+
+@pytest.mark.parametrize("shape,dil", [((1024, 256), 2), ((1024, 256), 1), ((512, 128), 1)])
+@pytest.mark.parametrize("B,S", [(8, 31), (3, 29), (10, 31)])
+def test_conv_seq_fused_triples(shape, dil, B, S):
+    """round 4: [conv2 3x3, conv3 + residual + ReLU, the next 1x1] of a Bottleneck as ONE tile routine on image-row tiles (c3c1_tile.inc,
+    FRONT = 1; smk_tune seq_fuse3) -- conv2's output never reaches memory and the barrier between conv2 and conv3 is gone.  A chain of
+    three identity blocks + adjust: the first triple's residual is the list input (requested in front of the wait), the later ones' is
+    the previous triple's conv3 output written by the SAME workgroup; dilation 1 and 2 (33 / 35-pixel padded rows), both layers'
+    shapes, idle teams (B = 3), two images on two of the teams (B = 10), 29-pixel rows.  Against the unfused list (itself held to the
+    oracle one layer deep): conv3's and the 1x1's outputs within fp16 summation-order noise; run twice: bit-identical."""
+    from siammask_amd import _lib
+    ops = _ops()
+    cin, planes = shape
+    rng = np.random.default_rng(131 + cin + B + dil)
+    x = rng.uniform(-1, 1, size=(B, cin, S, S)).astype(np.float32)
+    layers = _chain(rng, cin, planes, 3, dil)
+    xd = torch.from_numpy(x).cuda()
+    info = {}
+    old = _lib.tune_get("seq_fuse3")
+    try:
+        _lib.tune(seq_fuse3=1)
+        outs, _, _ = ops.conv_seq(xd, layers, info=info)
+        assert info["fused_pairs"] == 3 and _lib.tune_get("seq_fused3_last") == 3, (info, _lib.tune_get("seq_fused3_last"))
+        again, _, _ = ops.conv_seq(xd, layers, info=info)
+        _lib.tune(seq_fuse3=0)
+        plain, _, _ = ops.conv_seq(xd, layers, info=info)
+        assert _lib.tune_get("seq_fused3_last") == 0
+    finally:
+        _lib.tune(seq_fuse3=old)
+    _check(x, layers, plain, "unfused chain %s" % (shape,))
+    keep = [i for i in range(len(layers)) if i % 3 != 1 or i == len(layers) - 1]       # every record but the conv2s (never stored)
+    for i in keep:
+        assert torch.equal(outs[i], again[i]), "layer %d differs between two launches" % i
+        e = rel_err(outs[i].cpu().numpy(), plain[i].cpu().numpy().astype(np.float64))
+        assert e <= 3e-3, "%s dil %d B=%d S=%d: layer %d differs from the unfused list by %.2e" % (shape, dil, B, S, i, e)
+
+
+def test_conv_seq_triples_leave_short_rows_and_shared_conv2_outputs_alone():
+    """the template's 15 x 15 images keep the pairs (one image row would fill half a tile), and a conv2 whose output somebody else
+    reads as well must reach memory: no triple"""
+    from siammask_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(151)
+    old = _lib.tune_get("seq_fuse3")
+    try:
+        _lib.tune(seq_fuse3=1)
+        x = rng.uniform(-1, 1, size=(8, 1024, 15, 15)).astype(np.float32)
+        layers = _chain(rng, 1024, 256, 2, 2)
+        info = {}
+        outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers, info=info)
+        assert info["fused_pairs"] == 2 and _lib.tune_get("seq_fused3_last") == 0
+        _check(x, layers, outs, "15 x 15: pairs")
+        x = rng.uniform(-1, 1, size=(8, 1024, 31, 31)).astype(np.float32)
+        layers = _chain(rng, 1024, 256, 1, 2)
+        layers.append(dict(w=_w(rng, 256, 256, 1), b=rng.uniform(-1, 1, 256).astype(np.float32), relu=True, src=1))      # reads conv2's output too
+        outs, _, _ = ops.conv_seq(torch.from_numpy(x).cuda(), layers, info=info)
+        assert _lib.tune_get("seq_fused3_last") == 0
+        _check(x, layers, outs, "conv2 read twice: no triple")
+    finally:
+        _lib.tune(seq_fuse3=old)
