@@ -176,7 +176,7 @@ struct Tuning {
     int nchw_tn_major = 1;     // large NCHW f32 outputs (the 63x63 mask logits): tn-major tile order (see conv_params)
     int merge = 1;             // share one launch between independent convolutions (ds+c1, cls3+loc3, Refine windows): 0 never, 1 up to
                                // merge_max_batch streams (beyond it every member fills the chip by itself), 2 always
-    int merge_max_batch = 24;
+    int merge_max_batch = 32;
     int rf_wreg = 3;           // Refine's two merged front launches on the register-fed kernel's 64x64 tile: bit 0 the window convolutions + deconv, bit 1 the v*.2 launch
     int seq_fuse3 = 0;         // conv_seq_kernel: [conv2, conv3, next 1x1] of a Bottleneck as one tile routine on image-row tiles (0 off, 1 on, 2 layer3 only)
     int seq_spoll = 1;         // conv_seq_kernel's team barrier polls with s_load_dword glc (scalar path) instead of a vector sc1 load      // measured (profiles/r04k_merge_crossover_ab.txt): merging -5 % at B = 10, -1.5 % at B = 16, 0 at B = 24, +3.3 % at B = 32, +5.1 % at B = 64
