@@ -582,3 +582,31 @@ def test_conv_seq_triples_leave_short_rows_and_shared_conv2_outputs_alone():
         _check(x, layers, outs, "conv2 read twice: no triple")
     finally:
         _lib.tune(seq_fuse3=old)
+
+
+@pytest.mark.parametrize("B", [8, 12])
+def test_scalar_path_poll_gives_the_same_bits_and_clean_counters(B):
+    """round 4: the team barrier's poll through the scalar memory path (s_load_dword glc; smk_tune seq_spoll, default on) against the
+    vector sc1 load: only HOW a workgroup learns that the barrier is complete changes -- every output of the fused step bit-identical,
+    no failure reported, over several frames (the counters return to zero between launches either way)"""
+    from siammask_amd import _lib
+    old = _lib.tune_get("seq_spoll")
+    assert old == 1
+    outs = {}
+    try:
+        for v in (1, 0):
+            _lib.tune(seq_spoll=v)
+            m = _model(B)
+            z, x, twh = _step_inputs(B, 520)
+            m.template(z)
+            for _ in range(3):
+                o = m.track_step(x, twh, refine=True)
+            torch.cuda.synchronize()
+            grid, err = m.seq_status()
+            assert grid == 256 and err == 0, (grid, err)
+            outs[v] = {k: t.clone() for k, t in o.items() if t is not None}
+            del m
+    finally:
+        _lib.tune(seq_spoll=old)
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[0][k]), k
