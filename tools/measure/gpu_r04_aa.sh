@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/r04aa; mkdir -p $O
 export SMK_GRAPH=1
 B="python3 bench.py --steps 400 --warmup 20 --no-also --no-cpu-baseline --no-long"
 for rep in 1 2 3 4; do
-  for arm in product tabold; do
+  for arm in product chainold; do
     unset SMK_LIB; [ $arm != product ] && export SMK_LIB=$R/build_variants/$arm/libsiammask_hip.so
     timeout 120 $B 2>/dev/null | python -c "
 import json,sys
@@ -14,7 +14,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$arm', d['value'
   done
 done
 unset SMK_LIB
-for arm in product tabold; do
+for arm in product; do
   unset SMK_LIB; [ $arm != product ] && export SMK_LIB=$R/build_variants/$arm/libsiammask_hip.so
   echo "== $arm" | tee -a $O/chain_layers.txt
   SMK_GRAPH=0 SMK_CHAIN_CLK=1 timeout 120 python - <<'PY' 2>&1 | grep "refine_chain layers" | tail -2 | tee -a $O/chain_layers.txt
@@ -35,4 +35,4 @@ torch.cuda.synchronize()
 PY
 done
 unset SMK_LIB
-timeout 600 python -m pytest tests/test_gpu_e2e.py -x -q -k "refine or chain or bench_configuration" 2>&1 | grep -E "passed|failed|error" | tail -2 | tee $O/pytest.txt
+timeout 600 python -m pytest tests/test_gpu_e2e.py -x -q -k "refine or chain or bench_configuration or fp16_tight" 2>&1 | grep -E "passed|failed|error" | tail -2 | tee $O/pytest.txt
