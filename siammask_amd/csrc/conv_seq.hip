@@ -157,7 +157,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         const int halo_rpt = halo ? (cfg == SEQ_CFG_HALO128 ? 128 : 64) / L.Wo : 1;
         const int halo_tn = (L.Nst + 63) >> 6;
         const int tiles = fused3 ? L.Ho : fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
-        if (fusedp) {
+        if (T3 != 0 && fusedp) {
             // pair p = team slots 2p, 2p + 1; 64-row tiles dealt to the pairs (rows per tile evened out when one round covers the
             // image: 961 rows -> 16 tiles of 61); each pair counts its exchanges in bar[8 + p]
             const int npairs = nslots >> 1, pr = slot >> 1, hcu = slot & 1;
@@ -175,10 +175,12 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                     const int fm0 = img * hw + t * rt;
                     int fme = fm0 + rt;
                     if (fme > (img + 1) * hw) fme = (img + 1) * hw;
+                    if constexpr (T3 != 0) {
                     if (cfg == SEQ_CFG_C3C1P_L3)
                         alive = c3c1p_tile<256, 1024, 256, CLK>(L, a.L[li + 1], fm0, fme, a.B * hw, hcu, pr, npairs, cnt + 8 + pr, slabs, a, &ctl[2], &ctl[3], smem, tclk, w);
                     else
                         alive = c3c1p_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, fme, a.B * hw, hcu, pr, npairs, cnt + 8 + pr, slabs, a, &ctl[2], &ctl[3], smem, tclk, w);
+                    }
                 }
         } else {
         const int nk = L.Kpad >> 6;
@@ -217,9 +219,9 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 // two tiles at 64 rows; two ahead would need 234 + VGPRs and spill under this kernel's 256)
                 else if (cfg == 3) alive = wreg_tile<4, 4, 1, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 4) alive = wreg_tile<4, 2, 2, 3, 16, 1, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
-                else if (cfg == 9) alive = wreg_tile<4, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w);
+                else if (T3 != 0 && cfg == 9) { if constexpr (T3 != 0) alive = wreg_tile<4, 1, 4, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 64, smem, tclk, kt0, w); }     // (128x64: layer1 inside a sequence, smk_tune seq_first_stage)
                 // (measurement variant: 64x128 with a 5-deep activation ring and the weight fragments FOUR K tiles ahead)
-                else if (cfg == 5) alive = wreg_tile<2, 2, 2, 5, 16, 4, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);
+                else if (T3 != 0 && cfg == 5) { if constexpr (T3 != 0) alive = wreg_tile<2, 2, 2, 5, 16, 4, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w); }
 #ifdef SMK_MEASURE
                 // (measurement variants of the 64x128 tile, only in a library built with `make MEASURE=1`; results wrong by construction: 6 = activation tiles never refilled,
                 //  7 = weight fragments never refilled, 8 = no MFMA -- which stream sets the K-tile time inside a sequence?)
@@ -350,8 +352,13 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
         }
         if (a.L[li].sync && li + 1 < a.n) a.L[li].bar_ord = ++ord;
     }
+    // the product instantiation carries only the routines the default lists use; triples, pair splits and the deep-ring measurement
+    // tile live in the extended one (every routine the kernel carries costs the others registers: profiles/r04w_triples_ab.txt)
     bool triples = false;
-    for (int li = 0; li < a.n; ++li) triples = triples || a.L[li].cfg == SEQ_CFG_C2C3C1_L3 || a.L[li].cfg == SEQ_CFG_C2C3C1_L2;
+    for (int li = 0; li < a.n; ++li) {
+        const int cf = a.L[li].cfg;
+        triples = triples || cf == SEQ_CFG_C2C3C1_L3 || cf == SEQ_CFG_C2C3C1_L2 || cf == SEQ_CFG_C3C1P_L3 || cf == SEQ_CFG_C3C1P_L2 || cf == 5 || cf == 9;
+    }
     if (triples) {
         if (a.clk2) hipLaunchKernelGGL((conv_seq_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_seq_kernel<4, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
