@@ -134,7 +134,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         return;
     }
     unsigned pending = 0;                                // arrival count of the barrier arrived at and not yet waited for
-    const bool clk = a.clk && team == 0 && slot == 0 && threadIdx.x == 0;
+    const bool clk = CLK != 0 && a.clk && team == 0 && slot == 0 && threadIdx.x == 0;     // (the per-layer stamps live in the CLK build as well: SMK_SEQ_CLK=1 / 2 both launch it)
     if (clk) a.clk[0] = wall_clock64();
     bool alive = true;
     for (int li = 0; li < a.n && alive; ++li) {
@@ -360,9 +360,9 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
         triples = triples || cf == SEQ_CFG_C2C3C1_L3 || cf == SEQ_CFG_C2C3C1_L2 || cf == SEQ_CFG_C3C1P_L3 || cf == SEQ_CFG_C3C1P_L2 || cf == 5 || cf == 9;
     }
     if (triples) {
-        if (a.clk2) hipLaunchKernelGGL((conv_seq_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+        if (a.clk || a.clk2) hipLaunchKernelGGL((conv_seq_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_seq_kernel<4, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
-    } else if (a.clk2)                                    // SMK_SEQ_CLK=2: the build with the per-phase stamps (eager runs only)
+    } else if (a.clk || a.clk2)                           // SMK_SEQ_CLK=1 / 2: the build with the stamps (eager runs only)
         hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_seq_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -4;

@@ -2769,11 +2769,16 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    if (launch_conv_seq(a, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // The outputs and the timed launches come from the instantiation the engine's own lists run (no stamp pointers: the stamps
+    // live in the CLK build of the kernel); one more launch of the CLK build then writes the per-layer stamps (same results).
+    SeqArgs a_run = a;
+    a_run.clk = nullptr; a_run.clk2 = nullptr;
+    if (launch_conv_seq(a_run, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipEventRecord(e0, s));
     for (int it = 1; it < iters; ++it)
-        if (launch_conv_seq(a, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
+        if (launch_conv_seq(a_run, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipEventRecord(e1, s));
+    if (launch_conv_seq(a, grid, s)) return fail(SMK_E_HIP, "conv_seq launch failed: %s", hipGetErrorString(hipGetLastError()));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     if (iters > 1) HIPCHK(hipEventElapsedTime(&ms, e0, e1));
