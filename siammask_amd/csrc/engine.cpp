@@ -775,6 +775,7 @@ static bool seq_halo_ok(const ConvParams &p, int bm) {
 // force_halo: 0 = the rule below, 128 / 64 = that tile or fail, -1 = never (per-op tests that force another tile)
 static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L, int force_halo = 0) {
     if (!conv_wreg_eligible(p, dtype) || p.groups > 1 || p.pos || p.ups || p.Kpad % 128) return false;
+    if (p.ci_shift < 0 || p.Ci < 64) return false;       // (wreg_tile compiles the general tap arithmetic out of the sequence's routines)
     if (p.kh > 15 || p.kw > 15 || p.stride > 15 || p.pad > 15 || p.dil > 15) return false;
     // the packed record keeps the geometry in 16-bit fields
     const int u16[] = {p.Hs, p.Ws, p.Cs, p.cin_off, p.Ci, p.Hl, p.Wl, p.Ho, p.Wo, p.Kpad, p.Nst, p.Cos, p.cout_off, p.res_Cs, p.res_coff};

@@ -6,7 +6,7 @@ export SMK_GRAPH=1
 timeout 900 python -m pytest tests/test_gpu_seq.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $O/pytest_seq.txt
 B="python3 bench.py --steps 400 --warmup 20 --no-also --no-cpu-baseline --no-long"
 for rep in 1 2 3 4; do
-  for arm in product seqhead; do
+  for arm in product seqprev; do
     unset SMK_LIB; [ $arm != product ] && export SMK_LIB=$R/build_variants/$arm/libsiammask_hip.so
     timeout 120 $B 2>/dev/null | python -c "
 import json,sys
