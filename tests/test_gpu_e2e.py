@@ -579,8 +579,9 @@ def test_fused_step_is_deterministic_over_replays(B):
 
 
 def test_producer_variants_bit_equal_end_to_end():
-    """smk_tune a_stage (activation rows of conv_wreg / conv_seq through registers instead of LDS-DMA) and npw (two or four
-    producer waves) change the data path of the producers only: the fused B = 8 frame step (persistent sequences on) must
+    """smk_tune a_stage (activation rows of conv_wreg_kernel through registers instead of LDS-DMA; since the end of round 4 the persistent
+    sequence kernel no longer carries that arm -- every routine it carries costs the others registers -- and ignores the knob) and npw
+    (two or four producer waves) change the data path of the producers only: the fused B = 8 frame step (persistent sequences on) must
     give bit-identical outputs for every combination, and the device error flag of the sequences stays 0."""
     from siammask_amd import _lib
     B = 8
