@@ -61,7 +61,7 @@ def make_model(variant, dtype, batch, device):
 
 
 class Workload(object):
-    def __init__(self, name, device, rank, n_inputs=4, batch=None, fused=True):
+    def __init__(self, name, device, rank, n_inputs=4, batch=None, fused=True, pipeline=True):
         self.variant, self.B, self.dtype, self.refine = WORKLOADS[name]
         if batch:
             self.B = batch
@@ -80,6 +80,22 @@ class Workload(object):
         self.model.template(self.z)
         self.fused = fused
         self.last = None
+        # software-pipelined steps (smk_set_pipeline): the Refine / mask tail of frame f beside stem + layer1 of frame f + 1 -- the
+        # next crop depends on the decoded box only (tools/test.py:240-250,302-308).  Every frame's tail is inside the timed
+        # region: the loop ends with a device-wide synchronisation.
+        self.pipeline = bool(pipeline and fused and self.refine)
+        if self.pipeline:
+            self.model.set_pipeline(True)
+
+    def set_pipeline(self, on):
+        self.sync()
+        self.pipeline = bool(on and self.fused and self.refine)
+        self.model.set_pipeline(self.pipeline)
+
+    def join(self):
+        """order the current stream behind the last frame's Refine / mask tail (a no-op for serial steps)"""
+        if self.pipeline:
+            self.model.pipeline_join()
 
     def step(self, i):
         """One frame per stream.  fused: track_mask -> on-device decode (tools/test.py:205-254) ->
@@ -208,6 +224,8 @@ def timed_run(w, steps, warmup, world, gather, res=None):
         ev0.record()
     for i in range(steps):
         body(w, res, i)
+    if hasattr(w, "join"):
+        w.join()                                  # (pipelined steps: the last frame's tail belongs to the timed region)
     if cuda:
         ev1.record()
     t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (no device wait)
@@ -227,6 +245,31 @@ def timed_run(w, steps, warmup, world, gather, res=None):
     w.last_timing = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),
                      "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / steps, 4) if cuda else None}
     return dt
+
+
+def frame_latency(w, n=40):
+    """Per-frame latency beside the throughput, free-running steps, HIP events: `box` = from the moment frame f's crop can exist
+    (decode of frame f - 1 complete) to its decoded box; `mask` = to its Refine logits + 63x63 mask (for pipelined steps the tail
+    finishes on the side stream while the next frame's front end runs; a second stream is ordered behind it to time it)."""
+    s = torch.cuda.current_stream()
+    s2 = torch.cuda.Stream(device=w.device)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    for i in range(5):
+        w.step(i)
+    for i in range(n):
+        ev[i][0].record(s)
+        w.step(i)
+        ev[i][1].record(s)
+        if w.pipeline:
+            w.model.pipeline_join(s2)
+            ev[i][2].record(s2)
+        else:
+            ev[i][2].record(s)
+    w.sync()
+    box = sorted(e[0].elapsed_time(e[1]) for e in ev[5:])
+    mask = sorted(e[0].elapsed_time(e[2]) for e in ev[5:])
+    return {"box_ms_median": round(box[len(box) // 2], 4), "mask_ms_median": round(mask[len(mask) // 2], 4),
+            "mask_ms_max": round(mask[-1], 4), "pipelined": w.pipeline, "frames": len(box)}
 
 
 CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg"       # one convolution (or a merged batch) per launch
@@ -635,6 +678,8 @@ def main():
                     help="keep the per-frame results with two torch copies per step (round 1-3 form) instead of the library's result ring")
     ap.add_argument("--prewarm-seconds", type=float, default=2.0,
                     help="untimed clock/cache warm-up before the W warm-up steps")
+    ap.add_argument("--serial", action="store_true",
+                    help="serial frame steps (the round 1-4 form) instead of the software-pipelined ones (smk_set_pipeline)")
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference call sequence (track_mask, track_refine(fixed pos)) instead of the "
                          "fused device-resident step")
@@ -682,7 +727,8 @@ def main():
     if args.stub:
         w = StubWorkload(rank, batch=args.batch or 8)
     else:
-        w = Workload(args.workload, dev, rank, n_inputs=args.inputs, batch=args.batch, fused=not args.unfused)
+        w = Workload(args.workload, dev, rank, n_inputs=args.inputs, batch=args.batch, fused=not args.unfused,
+                     pipeline=not args.serial)
         w.no_ring = args.no_ring
     res = Results(w, args.steps)
     prewarm(w, res, 0.0 if args.stub else args.prewarm_seconds)
@@ -698,6 +744,20 @@ def main():
         d200 = timed_run(w, 200, 5, 1, gather, res200)
         long_run = {"steps": 200, "value": round(w.B * 200 / d200, 2), "ms_per_step": round(d200 / 200 * 1e3, 4)}
         del res200
+
+    latency = serial_cmp = None
+    if not args.stub and world == 1 and w.fused:
+        try:
+            latency = frame_latency(w)
+            if w.pipeline and not args.no_long:
+                # the same loop with serial steps (round 1-4 form) beside the pipelined `value`: what the overlap is worth on this box
+                w.set_pipeline(False)
+                ds = timed_run(w, args.steps, 5, 1, gather, res)
+                serial_cmp = {"fps": round(w.B * args.steps / ds, 2), "ms_per_step": round(ds / args.steps * 1e3, 4),
+                              "latency": frame_latency(w)}
+                w.set_pipeline(True)
+        except Exception as e:  # noqa: BLE001
+            latency = {"error": str(e)[:200]}
 
     seq = None
     if not args.stub:
@@ -737,7 +797,7 @@ def main():
                 prewarm(w2, res2, 0.5)
                 d2 = timed_run(w2, k2, 5, 1, gather, res2)
                 r2, _ = roofline(w2, 2)
-                also[name] = {"fps": round(w2.B * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3),
+                also[name] = {"fps": round(w2.B * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 3), "pipelined": w2.pipeline,
                               "mfma_frac": r2["frac"], "conv_tflops": r2["achieved"],
                               "host_enqueue_ms_per_step": w2.last_timing["host_enqueue_ms_per_step"]}
                 del w2, res2
@@ -782,10 +842,15 @@ def main():
                        "persistent_sequences": seq,
                        "results_kept_by": ("library result ring: one launch at the end of the step's graph (smk_set_result_ring)"
                                            if getattr(res, "ring", False) else "two torch copies per step"),
-                       "step": ("track_mask -> device decode -> track_refine, one graph" if w.fused
+                       "step": (("pipelined (smk_set_pipeline): [stem+layer1] | [layer2 .. heads -> device decode] on the step's stream, "
+                                 "[track_refine + mask head] of the same frame on a side stream beside the next frame's front end; "
+                                 "three graphs, two events per frame") if getattr(w, "pipeline", False) else
+                                "track_mask -> device decode -> track_refine, one graph" if w.fused
                                 else "track_mask ; track_refine(fixed pos)"),
                        "gflop_per_frame": w.gflop_per_frame()},
             "value_200_steps": long_run,
+            "latency": latency,
+            "serial_steps": serial_cmp,
             "roofline": roof,
             "cpu_baseline": cpu,
             "vendor_baseline": vendor,

@@ -58,6 +58,9 @@ typedef struct smk_ctx smk_ctx;
 #define SMK_E_WEIGHT     -3   /* unknown / missing / mis-shaped weight                     */
 #define SMK_E_HIP        -4   /* a HIP runtime call failed                                 */
 #define SMK_E_NODEVICE   -5   /* no gfx950 device visible                                  */
+#define SMK_E_SEQ        -6   /* the persistent sequence kernel reported a failure (ABI 1.5;
+                                 SMK_E_HIP before): frames enqueued since are invalid, the
+                                 context has switched to per-layer kernels, re-submit      */
 
 /* library/ABI version: major<<16 | minor */
 int smk_version(void);
@@ -140,19 +143,34 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
  * tools/test.py:296-311 keeps them per frame): with a ring set, every smk_step ends with ONE small launch that stores the
  * frame's decoded box [batch][8] f64 and its Refine logits [batch][127*127] as fp16 into row (frames committed % rows) of the
  * caller's device buffers box_ring [rows][batch][8] / refine_ring_f16 [rows][batch][127*127] and advances a device-side frame
- * counter -- part of the captured graph, no host work, no per-frame copies by the caller.  `batch` is that of the smk_step calls
- * (one batch size per ring).  refine_ring_f16 may be NULL (boxes only); rows = 0 switches the ring off.  Synchronises the device
- * and drops the captured graphs.  smk_result_ring_cursor synchronises `stream`, returns the number of frames committed and
- * optionally resets it. */
-int smk_set_result_ring(smk_ctx *ctx, double *box_ring_dev, void *refine_ring_f16_dev, int rows);
+ * counter -- part of the captured graph, no host work, no per-frame copies by the caller.  `batch` is the batch the rows were
+ * sized for (ABI 1.5: recorded; an smk_step with another batch fails with SMK_E_ARG instead of writing past the rows).
+ * refine_ring_f16 may be NULL (boxes only); rows = 0 switches the ring off.  Synchronises the device
+ * and drops the captured graphs.  smk_result_ring_cursor synchronises `stream` (behind an outstanding pipelined tail), returns
+ * the number of frames committed (mod 2^32) and optionally resets it. */
+int smk_set_result_ring(smk_ctx *ctx, double *box_ring_dev, void *refine_ring_f16_dev, int rows, int batch);
 int smk_result_ring_cursor(smk_ctx *ctx, int *frames_out, int reset, void *stream);
+
+/* Software-pipelined frame steps (ABI 1.5, additive).  The reference's tracker needs only the decoded box of frame f to crop
+ * frame f + 1 (tools/test.py:240-250,302-308); the Refine mask (:257-284) is an output.  smk_set_pipeline(ctx, 1) lets smk_step
+ * use that: a step with refine_out enqueues
+ *     on `stream`:       stem + layer1 of frame f | wait for the tail of frame f - 1 | layer2 .. heads .. decode of frame f
+ *     on a side stream:  the Refine module (+ the 63x63 mask head) of frame f at the decoded positions
+ * so that the small, low-occupancy launches of the tail share the chip with the bandwidth-bound front end of the next frame.
+ * Contract: cls / loc / box_out (and the ring's box row) of frame f are complete in `stream` order as before; mask_out /
+ * refine_out (and the ring's logits row + cursor) of frame f are complete once the NEXT smk_step's decode is, or behind
+ * smk_pipeline_join(ctx, any_stream), which orders that stream behind the outstanding tail (every other entry point of the
+ * context joins implicitly).  Results are bit-identical to the serial step.  Costs a second copy of p0 / p1 (4 MB per stream of the
+ * batch in fp16).  depth 0 = serial (default).  Synchronises the device. */
+int smk_set_pipeline(smk_ctx *ctx, int depth);
+int smk_pipeline_join(smk_ctx *ctx, void *stream);
 
 /* persistent per-XCD convolution sequences (fp16, batch 8: ResNet layer2 / layer3 / adjust run as ONE conv_seq_kernel launch,
  * one workgroup per CU, image b on XCD b % 8).  The kernel needs every workgroup resident at once; when that fails (a
  * neighbour that holds CUs for more than 0.2 s, a second persistent kernel beside it, an uneven XCD placement) it raises a
  * flag in host-mapped memory, abandons the remaining layers, and smk_seq_sync_check behind the call -- or, for callers that do
  * not use it, the NEXT entry point called on the context (smk_template / smk_track / smk_refine / smk_step /
- * smk_seq_status) -- returns SMK_E_HIP: the results enqueued since then are invalid,
+ * smk_seq_status) -- returns SMK_E_SEQ: the results enqueued since then are invalid,
  * sequences are switched off for the context (per-layer kernels from there on) and the caller re-submits the frame.
  * smk_seq_status synchronises the device and reports: grid_out = workgroups per launch (0: sequences are off -- the
  * placement / occupancy check at smk_create failed, or a failure was reported); err_out = last failure (0 none,

@@ -25,7 +25,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 # every symbol include/siammask_hip.h declares
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
-    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status", "smk_seq_sync_check", "smk_set_result_ring", "smk_result_ring_cursor",
+    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status", "smk_seq_sync_check", "smk_set_result_ring", "smk_result_ring_cursor", "smk_set_pipeline", "smk_pipeline_join",
     "smk_debug_read", "smk_debug_seq_inject", "smk_tune", "smk_tune_get", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_op_conv_seq", "smk_host_conv2d_ex", "smk_host_plan_conv", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
@@ -46,7 +46,10 @@ class SeqOp(ctypes.Structure):
 
 
 class SmkError(RuntimeError):
-    pass
+    code = 0      # the library's SMK_E_* return code (0: raised on the Python side)
+
+
+E_SEQ = -6        # SMK_E_SEQ: the persistent sequence kernel reported a failure; the frame is to be re-submitted
 
 
 def build_library(force=False, verbose=False):
@@ -90,7 +93,9 @@ def lib():
     L.smk_step.argtypes = [vp, fp, ci, ci, fp, fp, fp, fp, fp, fp, vp]
     L.smk_set_graph_mode.argtypes = [vp, ci]
     L.smk_debug_seq_inject.argtypes = [vp, ci]
-    L.smk_set_result_ring.argtypes = [vp, vp, vp, ci]
+    L.smk_set_result_ring.argtypes = [vp, vp, vp, ci, ci]
+    L.smk_set_pipeline.argtypes = [vp, ci]
+    L.smk_pipeline_join.argtypes = [vp, vp]
     L.smk_result_ring_cursor.argtypes = [vp, ctypes.POINTER(ci), ci, vp]
     L.smk_seq_sync_check.argtypes = [vp, vp, ctypes.POINTER(ci)]
     L.smk_tune.argtypes = [ctypes.c_char_p, ci]
@@ -129,7 +134,9 @@ def lib():
 def check(rc):
     if rc != 0:
         msg = lib().smk_last_error()
-        raise SmkError("libsiammask_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        e = SmkError("libsiammask_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+        e.code = rc
+        raise e
 
 
 def current_stream_ptr():

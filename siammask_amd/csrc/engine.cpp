@@ -300,6 +300,20 @@ struct smk_ctx {
     size_t prof_pool_next = 0;
     bool mask_join_pending = false;
     bool prof_split_l1 = false;      // (reserved) per-layer attribution of layer1 while profiling
+
+    // software-pipelined frame steps (smk_set_pipeline): the Refine / mask tail of frame f runs on pipe_stream beside the
+    // stem + layer1 launches of frame f + 1, which write the OTHER copy of p0 / p1 (the only tensors both sides touch)
+    int pipe_depth = 0;              // 0 = off, 1 = one tail in flight
+    int parity_now = 0;              // copy of p0 / p1 that act() resolves to (0 for every serial entry point)
+    int pipe_parity = 0;             // copy the next pipelined step writes
+    int last_parity = 0;             // copy the last tracked frame's p0 / p1 live in (smk_refine, smk_debug_read)
+    hipStream_t pipe_stream = nullptr;
+    std::vector<hipEvent_t> pipe_ev; // ring of events: "decode of frame f enqueued" / "tail of frame f enqueued"
+    size_t pipe_ev_next = 0;
+    bool tail_pending = false;       // a tail has been enqueued on pipe_stream and nothing has been ordered behind it yet
+    hipEvent_t tail_ev = nullptr;
+    int ring_batch = 0;              // batch the result ring was sized for (smk_set_result_ring)
+    bool pipe_tail_has_mask = false; // (A/B knob pipe_eager bit 1) mid's capture handed the mask head to the tail
 };
 
 static const char *dtname(int dt) { return dt == DT_F16 ? "f16" : "f32"; }
@@ -609,6 +623,9 @@ static int build_arena(smk_ctx *c) {
 
 static Act act(smk_ctx *c, const char *name, int H, int W, int C) {
     Act a;
+    // p0 / p1 exist twice while frame steps are pipelined (the tail of frame f reads one copy, the front of f + 1 writes the other)
+    if (c->parity_now && name[0] == 'p' && (name[1] == '0' || name[1] == '1') && !name[2]) a.p = c->buf.at(name[1] == '0' ? "p0#1" : "p1#1");
+    else
     a.p = c->buf.at(name);
     a.H = H; a.W = W; a.C = C;
     return a;
@@ -1117,7 +1134,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
 // The persistent kernel reports placement violations and barrier time-outs through a flag in host-mapped memory.  Every
 // entry point reads it (a plain host load, no synchronisation): on failure the context stops using sequences, the team
 // counters, the flags and every captured graph (they contain sequence launches) are reset, and the call fails with
-// SMK_E_HIP -- the results of the calls enqueued since the failure are not valid and the caller re-submits them.
+// SMK_E_SEQ -- the results of the calls enqueued since the failure are not valid and the caller re-submits them.
 static int seq_health(smk_ctx *c) {
     if (!c->seq_err_host) return 0;
     const int e = *(volatile int *)c->seq_err_host;
@@ -1133,9 +1150,10 @@ static int seq_health(smk_ctx *c) {
     c->graph_used.clear();
     c->graph_has_seq.clear();
     c->seq_pending = false;
+    c->tail_pending = false;                             // (the device has drained)
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
-    return fail(SMK_E_HIP, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
+    return fail(SMK_E_SEQ, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
                 "(the cached template included); persistent sequences are now off for this context (per-layer kernels from here "
                 "on): call template() again and re-submit the frame",
                 e == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out (another kernel held CUs "
@@ -1387,7 +1405,10 @@ static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act 
 // ---------------------------------------------------------------------------------------------
 // modified ResNet-50 + adjust (resnet.py:217-227, custom.py:19-25,58-66) on an S x S input.
 // S=255: leaves p0,p1,p2 (kept for Refine) and "search" [31,31,256];  S=127: leaves "zf" [7,7,256].
-static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s) {
+// phase: PH_FRONT = stem + maxpool + layer1 (p0, p1), PH_BACK = layer2 .. adjust from the kept p1; both = the whole backbone.
+// The pipelined frame step (smk_set_pipeline) runs the two halves as separate graphs.
+enum { PH_FRONT = 1, PH_BACK = 2, PH_ALL = 3 };
+static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s, int phase = PH_ALL) {
     const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
     const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
     const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
@@ -1395,7 +1416,9 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
     Act x1 = act(c, "x1", s1, s1, 64);
     auto stem_it = c->conv.find("stem");
     if (stem_it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv stem not packed");
-    if (c->dtype == DT_F16 && g_tune.stem_fused && stem_it->second.w_frag) {
+    if (!(phase & PH_FRONT)) {
+        // the front half ran as its own graph: p1 is where it left it
+    } else if (c->dtype == DT_F16 && g_tune.stem_fused && stem_it->second.w_frag) {
         // one launch: frame -> p0 (kept for Refine) -> pooled x1, the p0 tile never leaves LDS in between (stem_pool.hip)
         StemPoolParams sp_{x, stem_it->second.w_frag, stem_it->second.bias, p0.p, x1.p, B, S, s0, s1, stem_it->second.Kpad};
         ProfScope ps(c, s, "stem_pool", "stem_pool", 2.0 * B * s0 * s0 * 64.0 * 147.0,
@@ -1432,6 +1455,8 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s)
     for (int st = 0; st < 3; ++st) {
         // layer1 stays on the per-launch kernels: short K and 63 tiles of 64 rows per image (two rounds for 32 workgroups)
         // made it 140 us inside the sequence against 96 us as launches (SMK_SEQ_CLK, profiles/r02_seq_ab.txt)
+        if (st == 0 && !(phase & PH_FRONT)) { cur = act(c, "p1", s1, s1, 256); continue; }
+        if (st == 1 && !(phase & PH_BACK)) { c->last_B = B; c->last_S = S; return 0; }
         if (seq_ok && st == g_tune.seq_first_stage) c->seq_on = true;
         const int planes = STAGE_PLANES[st];
         for (int b = 0; b < STAGE_BLOCKS[st]; ++b) {
@@ -1571,8 +1596,8 @@ static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
 // to a side stream and only joined by the caller at the end of the frame step, so that it runs
 // beside the small decode / Refine launches instead of in front of them
 static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
-                     hipStream_t s, bool defer_mask_join = false) {
-    CHK(run_backbone(c, x, B, 255, s));
+                     hipStream_t s, bool defer_mask_join = false, int phase = PH_ALL) {
+    CHK(run_backbone(c, x, B, 255, s, phase));
     const int nbt = nbranch(c);                                   // branches laid out in the buffers
     const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
     Act se = act(c, "search", 31, 31, 256);
@@ -1814,44 +1839,70 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // graph capture / replay
 // ---------------------------------------------------------------------------------------------
+// capture `body` into an instantiated graph under `key` (LRU-bounded cache); no launch
 template <typename F>
-static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&body) {
-    if (!c->graph_mode || c->prof) return body(s);
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
-        if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-        const bool pend0 = c->seq_pending;
-        c->cap_has_seq = false;
-        int rc = body(c->cap_stream);
-        const bool has_seq = c->cap_has_seq;
-        c->seq_pending = pend0;                          // captured, not enqueued
-        hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess) return fail(SMK_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        hipGraphExec_t ex = nullptr;
-        e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (e != hipSuccess) return fail(SMK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-        // bound the cache: drop the least recently used graph (a caller that hands over fresh I/O buffers every frame
-        // re-captures every frame anyway -- that is what the staging path is for -- but it must not evict the graphs
-        // of callers with stable buffers)
-        while (c->graphs.size() >= 64) {
-            auto lru = c->graph_used.begin();
-            for (auto u = c->graph_used.begin(); u != c->graph_used.end(); ++u)
-                if (u->second < lru->second) lru = u;
-            auto g = c->graphs.find(lru->first);
-            if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
-            c->graph_has_seq.erase(lru->first);
-            c->graph_used.erase(lru);
-        }
-        it = c->graphs.emplace(key, ex).first;
-        c->graph_has_seq[key] = has_seq;
+static int capture_graph(smk_ctx *c, const GraphKey &key, F &&body) {
+    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    const bool pend0 = c->seq_pending;
+    c->cap_has_seq = false;
+    int rc = body(c->cap_stream);
+    const bool has_seq = c->cap_has_seq;
+    c->seq_pending = pend0;                          // captured, not enqueued
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(SMK_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(SMK_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    // bound the cache: drop the least recently used graph (a caller that hands over fresh I/O buffers every frame
+    // re-captures every frame anyway -- that is what the staging path is for -- but it must not evict the graphs
+    // of callers with stable buffers)
+    while (c->graphs.size() >= 64) {
+        auto lru = c->graph_used.begin();
+        for (auto u = c->graph_used.begin(); u != c->graph_used.end(); ++u)
+            if (u->second < lru->second) lru = u;
+        auto g = c->graphs.find(lru->first);
+        if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
+        c->graph_has_seq.erase(lru->first);
+        c->graph_used.erase(lru);
     }
+    c->graphs.emplace(key, ex);
+    c->graph_has_seq[key] = has_seq;
+    c->graph_used[key] = ++c->graph_tick;
+    return 0;
+}
+
+static int launch_graph(smk_ctx *c, const GraphKey &key, hipStream_t s) {
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) return fail(SMK_E_STATE, "internal: graph not captured");
     c->graph_used[key] = ++c->graph_tick;
     HIPCHK(hipGraphLaunch(it->second, s));
     if (c->graph_has_seq[key]) c->seq_pending = true;
+    return 0;
+}
+
+template <typename F>
+static int run_maybe_graph(smk_ctx *c, const GraphKey &key, hipStream_t s, F &&body) {
+    if (!c->graph_mode || c->prof) return body(s);
+    if (c->graphs.find(key) == c->graphs.end()) CHK(capture_graph(c, key, body));
+    return launch_graph(c, key, s);
+}
+
+static void drop_graph(smk_ctx *c, const GraphKey &key) {
+    auto g = c->graphs.find(key);
+    if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
+    c->graph_has_seq.erase(key);
+    c->graph_used.erase(key);
+}
+
+// order `s` behind the Refine / mask tail a pipelined smk_step left on the side stream (no-op when there is none)
+static int pipe_join(smk_ctx *c, hipStream_t s, bool clear) {
+    if (!c->tail_pending) return 0;
+    HIPCHK(hipStreamWaitEvent(s, c->tail_ev, 0));
+    if (clear) c->tail_pending = false;
     return 0;
 }
 
@@ -1883,7 +1934,7 @@ static int seq_grid_for(int ncu) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 4; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
+int smk_version(void) { return (1 << 16) | 5; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
                                                   // sequence failures reported at the next entry point
 
 const char *smk_last_error(void) { return g_err.c_str(); }
@@ -1931,6 +1982,7 @@ int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch)
 int smk_destroy(smk_ctx *c) {
     if (!c) return 0;
     hipSetDevice(c->device);
+    if (c->pipe_stream) hipStreamSynchronize(c->pipe_stream);   // a tail may still read the arena
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf)
@@ -1951,6 +2003,8 @@ int smk_destroy(smk_ctx *c) {
     for (auto &e : c->ev_pool) hipEventDestroy(e);
     for (auto &e : c->prof_pool) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (c->side[i]) hipStreamDestroy(c->side[i]);
+    for (auto &e : c->pipe_ev) hipEventDestroy(e);
+    if (c->pipe_stream) hipStreamDestroy(c->pipe_stream);
     delete c;
     return 0;
 }
@@ -2144,6 +2198,8 @@ int smk_template(smk_ctx *c, const float *z, int B, void *stream) {
     HIPCHK(hipSetDevice(c->device));
     CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
+    CHK(pipe_join(c, s, true));
+    c->parity_now = c->last_parity = 0;
     GraphKey key{0, B, 0, {z}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_template(c, z, B, st); });
     if (rc) return rc;
@@ -2166,6 +2222,8 @@ int smk_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *l
     HIPCHK(hipSetDevice(c->device));
     CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
+    CHK(pipe_join(c, s, true));
+    c->parity_now = c->last_parity = 0;
     GraphKey key{1, B, flags, {x, cls, loc, mask}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_track(c, x, B, flags, cls, loc, mask, st); });
     if (rc) return rc;
@@ -2181,6 +2239,8 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
     HIPCHK(hipSetDevice(c->device));
     CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
+    CHK(pipe_join(c, s, true));
+    c->parity_now = c->last_parity;          // the copy of p0 / p1 the last tracked frame left its features in
     if (!on_device) {
         for (int i = 0; i < 2 * B; ++i)
             if (pos[i] < 0 || pos[i] >= 25) return fail(SMK_E_ARG, "smk_refine: pos[%d]=%d outside [0,25)", i, pos[i]);
@@ -2188,7 +2248,7 @@ int smk_refine(smk_ctx *c, const int32_t *pos, int on_device, int B, float *out,
     } else {
         HIPCHK(hipMemcpyAsync(c->pos_dev, pos, sizeof(int) * 2 * B, hipMemcpyDeviceToDevice, s));
     }
-    GraphKey key{2, B, 0, {out}};
+    GraphKey key{2, B, c->parity_now, {out}};
     return run_maybe_graph(c, key, s, [&](hipStream_t st) { return seq_refine(c, B, out, st); });
 }
 
@@ -2246,6 +2306,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "wreg_policy")) { if (value != 0 && value != 1) return fail(SMK_E_ARG, "wreg_policy 0|1"); g_tune.wreg_policy = value; }
     else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
+    else if (!strcmp(key, "pipe_eager")) g_tune.pipe_eager = value & 3;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
@@ -2273,7 +2334,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2379,7 +2440,107 @@ int smk_decode(smk_ctx *c, const float *cls, const float *loc, int B, const doub
     if (!c || !cls || !loc || !target_wh) return fail(SMK_E_ARG, "smk_decode: null argument");
     if (B < 1 || B > c->maxB) return fail(SMK_E_ARG, "smk_decode: batch %d not in [1,%d]", B, c->maxB);
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_join(c, (hipStream_t)stream, true));     // (a tail in flight reads the ctx-internal position)
     return seq_decode(c, cls, loc, B, target_wh, pos_out ? pos_out : c->pos_dev, box_out, (hipStream_t)stream);
+}
+
+// the part of a frame step that feeds the NEXT frame (its crop depends on the decoded box only, tools/test.py:240-250,302-308):
+// layer2 .. decode; `phase` = PH_ALL with the front end in front of it (serial step) or PH_BACK behind a front graph
+static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
+                             float *mask, double *box_out, float *refine_out, hipStream_t st, bool defer_mask_join, int phase) {
+    // sharp fp16 with Refine: the mask head rides in the Refine chain launch (see chain_mask_kernel)
+    c->have_deferred_mask = false;
+    c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
+                        c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
+                        B <= 16;      // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
+    int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, defer_mask_join, phase);
+    c->defer_mask_req = false;
+    CHK(rc2);
+    // result ring (smk_set_result_ring): the decode launch writes the box row, the Refine chain launch the fp16 logits and
+    // advances the cursor; only a Refine that does NOT end in the chain kernel (fp32, smk_tune chain = 0) needs the
+    // stand-alone commit launch for its logits
+    c->ring_in_step = c->ring_rows > 0;
+    c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
+    c->ring_ref_folded = false;
+    int rcd = seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st);
+    c->ring_in_step = false;
+    return rcd;
+}
+
+// the part nothing on the device waits for (tools/test.py:257-284: the mask is an output): Refine at the decoded positions
+// (+ the 63x63 mask head when the chain launch carries it) and the ring row's logits
+static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *refine_out, hipStream_t st) {
+    c->ring_in_step = c->ring_rows > 0;
+    c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
+    int rcd = refine_out ? seq_refine(c, B, refine_out, st) : 0;
+    c->ring_in_step = false;
+    CHK(rcd);
+    if (c->have_deferred_mask) {                 // the chain launch did not take it (timing aid on, ...): its own launch
+        c->have_deferred_mask = false;
+        Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
+        ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
+        CHK(run_conv(c, "mask3", h0, nullptr, B, om, st));
+    }
+    if (c->mask_join_pending) {
+        c->mask_join_pending = false;
+        CHK(stream_dep(c, c->side[0], st));
+    }
+    if (c->ring_rows > 0 && refine_out && c->ring_ref && !c->ring_ref_folded) {      // (the box row was written by the decode launch)
+        RingParams rg{box_out, refine_out, nullptr, (_Float16 *)c->ring_ref, c->ring_cursor,
+                      (unsigned *)(c->ring_cursor + 1), c->ring_rows, B, 127 * 127};
+        ProfScope ps(c, st, "ring_commit", "ring_commit", 0.0, (double)B * (64.0 * 2 + (refine_out ? 127.0 * 127 * 6 : 0.0)));
+        if (launch_ring_commit(rg, st)) return fail(SMK_E_HIP, "ring_commit launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}
+
+// Pipelined frame step (smk_set_pipeline(ctx, 1)): three linear graphs and two events per frame --
+//   caller's stream:  front(f) = stem + layer1 into copy f % 2 of p0 / p1 | wait tail(f-1) | mid(f) = layer2 .. decode
+//   side stream:      wait mid(f) | tail(f) = Refine (+ mask head) at the decoded positions
+// tail(f) (small launches, low occupancy) shares the chip with front(f+1) (bandwidth-bound); the persistent layer2 .. adjust launch of
+// frame f + 1 waits for tail(f) so that it still owns every CU.  front(f+1) is ordered behind decode(f) by the caller's stream, as a
+// tracker that crops frame f + 1 at the decoded box needs it.  Everything both sides touch is either written by mid (after the wait)
+// or exists twice (p0, p1).
+static int step_pipelined(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
+                          float *mask, double *box_out, float *refine_out, hipStream_t s) {
+    const int par = c->pipe_parity;
+    c->parity_now = par;
+    int64_t pk, wi;
+    memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
+    const std::vector<const void *> io{x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi};
+    const GraphKey kf{10, B, flags | (par << 16), io}, km{11, B, flags | (par << 16), io}, kt{12, B, flags | (par << 16), io};
+    auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
+    auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
+    auto tail = [&](hipStream_t st) { return step_tail(c, B, mask, box_out, refine_out, st); };
+    const bool graphs = c->graph_mode;
+    if (graphs && !(c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt))) {
+        // the three are captured together: mid hands the mask head over to tail at capture time
+        drop_graph(c, kf); drop_graph(c, km); drop_graph(c, kt);
+        CHK(capture_graph(c, kf, front));
+        CHK(capture_graph(c, km, mid));
+        c->pipe_tail_has_mask = c->have_deferred_mask;
+        CHK(capture_graph(c, kt, tail));
+        if (!(c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt))) return fail(SMK_E_STATE, "internal: pipelined step graphs evicted while capturing");
+    }
+    CHK((graphs && !(g_tune.pipe_eager & 1)) ? launch_graph(c, kf, s) : front(s));
+    CHK(pipe_join(c, s, true));
+    CHK(graphs ? launch_graph(c, km, s) : mid(s));
+    hipEvent_t e_dec = c->pipe_ev[c->pipe_ev_next++ % c->pipe_ev.size()];
+    hipEvent_t e_tail = c->pipe_ev[c->pipe_ev_next++ % c->pipe_ev.size()];
+    HIPCHK(hipEventRecord(e_dec, s));
+    HIPCHK(hipStreamWaitEvent(c->pipe_stream, e_dec, 0));
+    if (graphs && !(g_tune.pipe_eager & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
+    else {
+        // (eager: mid's capture-time hand-over of the mask head is replayed from the context, see step_track_decode)
+        if (graphs) c->have_deferred_mask = c->pipe_tail_has_mask;
+        CHK(tail(c->pipe_stream));
+    }
+    HIPCHK(hipEventRecord(e_tail, c->pipe_stream));
+    c->tail_ev = e_tail;
+    c->tail_pending = true;
+    c->last_parity = par;
+    c->pipe_parity = par ^ 1;
+    return 0;
 }
 
 int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
@@ -2392,59 +2553,68 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
         return fail(SMK_E_ARG, "smk_step: refine needs the sharp variant and SMK_TRACK_MASK");
     if ((flags & SMK_TRACK_MASK) && c->variant == SMK_VARIANT_RPN) return fail(SMK_E_ARG, "smk_step: rpn has no mask branch");
     if ((flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) && !mask) return fail(SMK_E_ARG, "smk_step: mask_out is NULL");
+    if (c->ring_rows > 0 && B != c->ring_batch)
+        return fail(SMK_E_ARG, "smk_step: batch %d, but the result ring was set for batch %d (smk_set_result_ring)", B, c->ring_batch);
     HIPCHK(hipSetDevice(c->device));
     CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
+    // pipelined: only a step with a Refine tail has something to overlap; the profiler times launches one by one; the fork / join
+    // concurrency knob and a persistent sequence that includes layer1 (measurement knobs) keep the serial step
+    if (c->pipe_depth > 0 && refine_out && !c->prof && !parallel_ok(c) && g_tune.seq_first_stage >= 1 && !g_tune.mask_overlap) {
+        int rc = step_pipelined(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, s);
+        if (rc) return rc;
+        c->track_B = B;
+        return 0;
+    }
+    CHK(pipe_join(c, s, true));
+    c->parity_now = c->last_parity = 0;
     int64_t pk, wi;
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     GraphKey key{3, B, flags, {x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi}};
     int rc = run_maybe_graph(c, key, s, [&](hipStream_t st) {
-        // sharp fp16 with Refine: the mask head rides in the Refine chain launch (see chain_mask_kernel)
-        c->have_deferred_mask = false;
-        c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
-                            c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
-                            B <= 16;      // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
-        int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, true);
-        c->defer_mask_req = false;
-        CHK(rc2);
-        // result ring (smk_set_result_ring): the decode launch writes the box row, the Refine chain launch the fp16 logits and
-        // advances the cursor; only a Refine that does NOT end in the chain kernel (fp32, smk_tune chain = 0) needs the
-        // stand-alone commit launch for its logits
-        c->ring_in_step = c->ring_rows > 0;
-        c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
-        c->ring_ref_folded = false;
-        int rcd = seq_decode(c, cls, loc, B, target_wh, c->pos_dev, box_out, st);
-        if (!rcd && refine_out) rcd = seq_refine(c, B, refine_out, st);
-        c->ring_in_step = false;
-        CHK(rcd);
-        if (c->have_deferred_mask) {                 // the chain launch did not take it (timing aid on, ...): its own launch
-            c->have_deferred_mask = false;
-            Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
-            ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
-            CHK(run_conv(c, "mask3", h0, nullptr, B, om, st));
-        }
-        if (c->mask_join_pending) {
-            c->mask_join_pending = false;
-            CHK(stream_dep(c, c->side[0], st));
-        }
-        if (c->ring_rows > 0 && refine_out && c->ring_ref && !c->ring_ref_folded) {      // (the box row was written by the decode launch)
-            RingParams rg{box_out, refine_out, nullptr, (_Float16 *)c->ring_ref, c->ring_cursor,
-                          (unsigned *)(c->ring_cursor + 1), c->ring_rows, B, 127 * 127};
-            ProfScope ps(c, st, "ring_commit", "ring_commit", 0.0, (double)B * (64.0 * 2 + (refine_out ? 127.0 * 127 * 6 : 0.0)));
-            if (launch_ring_commit(rg, st)) return fail(SMK_E_HIP, "ring_commit launch failed: %s", hipGetErrorString(hipGetLastError()));
-        }
-        return 0;
+        CHK(step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, true, PH_ALL));
+        return step_tail(c, B, mask, box_out, refine_out, st);
     });
     if (rc) return rc;
     c->track_B = (flags & SMK_TRACK_MASK) ? B : 0;
     return 0;
 }
 
-int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int rows) {
+int smk_set_pipeline(smk_ctx *c, int depth) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
-    if (rows < 0 || (rows > 0 && !box_ring)) return fail(SMK_E_ARG, "smk_set_result_ring: rows %d / box ring %p", rows, (void *)box_ring);
+    if (depth < 0 || depth > 1) return fail(SMK_E_ARG, "smk_set_pipeline: depth %d (0 = off, 1 = one Refine / mask tail in flight)", depth);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
+    c->tail_pending = false;
+    if (depth > 0) {
+        if (!c->buf.count("p0#1")) {
+            CHK(alloc_buf(c, "p0#1", c->buf_elems.at("p0")));
+            CHK(alloc_buf(c, "p1#1", c->buf_elems.at("p1")));
+        }
+        if (!c->pipe_stream) HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+        if (c->pipe_ev.empty()) {
+            c->pipe_ev.resize(16);
+            for (auto &e : c->pipe_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+    c->pipe_depth = depth;
+    c->pipe_parity = 0;
+    return 0;
+}
+
+int smk_pipeline_join(smk_ctx *c, void *stream) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    return pipe_join(c, (hipStream_t)stream, false);
+}
+
+int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int rows, int batch) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    if (rows < 0 || (rows > 0 && !box_ring)) return fail(SMK_E_ARG, "smk_set_result_ring: rows %d / box ring %p", rows, (void *)box_ring);
+    if (rows > 0 && (batch < 1 || batch > c->maxB)) return fail(SMK_E_ARG, "smk_set_result_ring: batch %d not in [1,%d]", batch, c->maxB);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    c->tail_pending = false;
     // the captured step graphs carry the ring pointers (or no commit launch at all): start over
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
@@ -2455,12 +2625,14 @@ int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int
     c->ring_box = rows ? box_ring : nullptr;
     c->ring_ref = rows ? refine_ring_f16 : nullptr;
     c->ring_rows = rows;
+    c->ring_batch = rows ? batch : 0;
     return 0;
 }
 
 int smk_result_ring_cursor(smk_ctx *c, int *frames_out, int reset, void *stream) {
     if (!c || !c->ring_cursor) return fail(SMK_E_STATE, "smk_result_ring_cursor: no result ring set");
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_join(c, (hipStream_t)stream, true));        // the cursor is advanced by the tail of the last pipelined step
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (frames_out) HIPCHK(hipMemcpy(frames_out, c->ring_cursor, sizeof(int), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(c->ring_cursor, 0, 2 * sizeof(int)));
@@ -2495,7 +2667,9 @@ int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int
             if (W) *W = e.w;
             if (!dst) return 0;
             if (c->last_B < 1) return fail(SMK_E_STATE, "smk_debug_read: nothing has run yet");
-            CvtOutParams p{c->buf.at(e.b), dst, c->last_B, e.cn, e.h, e.w, e.cs, 0};
+            CHK(pipe_join(c, (hipStream_t)stream, true));
+            c->parity_now = c->last_parity;            // p0 / p1: the copy the last tracked frame wrote
+            CvtOutParams p{act(c, e.b, e.h, e.w, e.cs).p, dst, c->last_B, e.cn, e.h, e.w, e.cs, 0};
             if (launch_cvt_out(p, c->dtype, stream)) return fail(SMK_E_HIP, "cvt_out launch failed");
             return 0;
         }

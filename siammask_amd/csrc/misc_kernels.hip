@@ -554,7 +554,7 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
         // result ring: this frame's box also goes to the ring's current row (the cursor was advanced by the previous frame's
         // last launch: a plain read).  Without a Refine launch behind it the last stream to get here advances the cursor --
         // every other stream's writer has read it before its own arrival.
-        const int row = *(volatile const int *)p.ring_cursor % p.ring_rows;
+        const int row = (int)(*(volatile const unsigned *)p.ring_cursor % (unsigned)p.ring_rows);   // unsigned: no negative row after 2^31 frames
         double *r = p.ring_box + ((size_t)row * p.B + b) * 8;
         const double *o = p.box_out + 8 * b;
         for (int q = 0; q < 8; ++q) r[q] = o[q];
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_kernel(const DecodeParams 
 // zero for the next graph replay.  16-byte loads, 8-byte stores; 0.8 MB at B = 8.
 __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
     __shared__ int row_sh;
-    if (threadIdx.x == 0) row_sh = *(volatile const int *)p.cursor % p.rows;      // (written by the previous step's launch: visible across the kernel boundary)
+    if (threadIdx.x == 0) row_sh = (int)(*(volatile const unsigned *)p.cursor % (unsigned)p.rows);      // (written by the previous step's launch: visible across the kernel boundary)
     __syncthreads();
     const size_t row = (size_t)row_sh;
     const size_t nref = (size_t)p.B * p.n;

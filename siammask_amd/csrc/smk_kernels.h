@@ -213,6 +213,8 @@ struct Tuning {
                                // waves), 1 = the rule fitted with four (wreg_choice)
     int npw = 4;               // conv_wreg / conv_seq: producer waves per workgroup (2 or 4; measured: profiles/r02_producer_waves_2_vs_4.txt)
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
+    int pipe_eager = 0;        // pipelined frame step, A/B knob: bit 0 = the front end (stem + layer1) as eager launches instead of a graph,
+                               // bit 1 = the Refine / mask tail as eager launches
 };
 extern Tuning g_tune;
 

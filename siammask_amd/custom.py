@@ -231,6 +231,10 @@ class Custom(nn.Module):
         self._fast = {}
         self.zf = None
         self._tracked = 0
+        # the ring, the pipeline mode and the replay closures belonged to that context
+        self._ring = None
+        self._replay = {}
+        self._pipeline = False
 
     def __del__(self):
         try:
@@ -279,11 +283,16 @@ class Custom(nn.Module):
         except _lib.SmkError as e:
             # (raised by the check behind the call, or by the entry point itself when an earlier, unguarded call -- the
             #  asynchronous track_step -- left the flag set)
-            if "conv_seq_kernel reported" not in str(e):
+            if e.code != _lib.E_SEQ:
                 raise
-        self.seq_recovered += 1
+            failure = e
         order = ("template", "track", "refine")
-        for st in order[:order.index(stage)]:
+        need = order[:order.index(stage)]
+        if any(self._replay.get(st) is None for st in need):
+            # (e.g. template(); track_step(); track_refine(pos): no track() of THIS frame was recorded -- nothing valid to re-run)
+            raise failure
+        self.seq_recovered += 1
+        for st in need:
             self._replay[st]()
         once()
 
@@ -413,6 +422,8 @@ class Custom(nn.Module):
                 self._fast[key] = self._fast.pop(key)    # most recently used last
                 args, out = hit
                 _lib.check(self._smk_step(self._ctx, *args, _lib.current_stream_ptr()))
+                if "track" in self._replay:
+                    del self._replay["track"]
                 return out
         self._ensure(search, B)
         self._push_hp()
@@ -445,6 +456,7 @@ class Custom(nn.Module):
             self._smk_step = _lib.lib().smk_step
             _lib.check(self._smk_step(self._ctx, *args, _lib.current_stream_ptr()))
         self._tracked = B if self.variant != "rpn" else 0
+        self._replay.pop("track", None)      # the recorded track() is not the frame the context holds any more (see _guarded)
         out = {"cls": cls, "loc": loc, "mask": mask, "box": box, "refine": ref}
         if not stage and self._graph:
             self._fast.pop(key, None)
@@ -464,15 +476,34 @@ class Custom(nn.Module):
         dev = torch.device("cuda", self._ctx_device)
         self._fast = {}
         if rows <= 0:
-            _lib.check(_lib.lib().smk_set_result_ring(self._ctx, None, None, 0))
+            _lib.check(_lib.lib().smk_set_result_ring(self._ctx, None, None, 0, 0))
             self._ring = None
             return None, None
         with torch.cuda.device(self._ctx_device):
             box = torch.zeros((rows, B, 8), dtype=torch.float64, device=dev)
             ref = torch.zeros((rows, B, spec.REFINE_OUT ** 2), dtype=torch.float16, device=dev) if refine else None
-        _lib.check(_lib.lib().smk_set_result_ring(self._ctx, box.data_ptr(), ref.data_ptr() if ref is not None else None, rows))
+        _lib.check(_lib.lib().smk_set_result_ring(self._ctx, box.data_ptr(), ref.data_ptr() if ref is not None else None, rows, B))
         self._ring = (box, ref, B)
         return box, ref
+
+    def set_pipeline(self, on=True):
+        """Software-pipeline track_step (smk_set_pipeline): the Refine / mask tail of frame f runs on a side stream beside the
+        stem + layer1 launches of frame f + 1 -- the next frame's crop only needs the decoded box (tools/test.py:240-250,302-308),
+        the mask is an output (:257-284).  ``box`` / ``cls`` / ``loc`` of a track_step are complete in stream order as before;
+        ``refine`` / ``mask`` (and the ring's logits row) of frame f are complete behind ``pipeline_join()`` or once the next
+        track_step's box is.  Bit-identical to the serial step."""
+        if self._ctx is None:
+            raise RuntimeError("set_pipeline(): run template() first")
+        _lib.check(_lib.lib().smk_set_pipeline(self._ctx, 1 if on else 0))
+        self._pipeline = bool(on)
+
+    def pipeline_join(self, stream=None):
+        """Order ``stream`` (default: the current stream) behind the outstanding Refine / mask tail of the last pipelined
+        track_step; a no-op when there is none."""
+        if self._ctx is None:
+            return
+        sp = _lib.current_stream_ptr() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        _lib.check(_lib.lib().smk_pipeline_join(self._ctx, sp))
 
     def result_ring_frames(self, reset=False):
         """frames committed to the ring so far (synchronises the current stream)"""

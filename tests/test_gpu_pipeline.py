@@ -1,0 +1,129 @@
+"""Software-pipelined frame steps (smk_set_pipeline, ABI 1.5).
+
+The reference's tracker crops frame f + 1 at the box decoded from frame f (/root/reference/tools/test.py:240-250,302-308);
+the Refine mask (:257-284) is an output nothing on the device waits for.  The pipelined step runs Refine (+ the 63x63 mask
+head) of frame f on a side stream beside stem + layer1 of frame f + 1.  It must change WHEN things run and nothing else:
+every output and every ring row bit-identical to the serial step."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from siammask_amd import _lib, spec, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(B, dtype="f16"):
+    from siammask_amd.custom import build
+    m = build("sharp", dtype=dtype, graph=True, max_batch=B)
+    m.load_state_dict(synth.torch_state_dict("sharp", "synthetic_damped"))
+    return m.eval().cuda()
+
+
+def _inputs(B, n, seed):
+    z = torch.from_numpy(synth.smooth_image_batch(B, 127, stream0=seed)).cuda()
+    xs = [torch.from_numpy(synth.smooth_image_batch(B, 255, stream0=seed + 7 * i)).cuda() for i in range(n)]
+    g = np.random.Generator(np.random.PCG64(seed))
+    twh = torch.from_numpy(g.uniform(40.0, 110.0, size=(B, 2))).cuda()
+    return z, xs, twh
+
+
+@pytest.mark.parametrize("B,dtype,frames", [(8, "f16", 7), (64, "f16", 4), (1, "f16", 5), (8, "f32", 3), (3, "f16", 4)])
+def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
+    """ring rows (box f64 + fp16 Refine logits) and the step's own outputs, frame by frame, serial vs pipelined -- B = 8 runs
+    layer2 .. adjust as the persistent sequence (which waits for the tail), B = 64 / 1 / 3 the per-launch kernels, fp32 ends
+    its Refine in the stand-alone ring commit launch"""
+    m = _model(B, dtype)
+    z, xs, twh = _inputs(B, frames, 500 + B)
+    m.template(z)
+    box, ref = m.set_result_ring(frames, batch=B)
+    outs = []
+    for x in xs:
+        o = m.track_step(x, twh, refine=True, stage=False)
+        torch.cuda.synchronize()
+        outs.append({k: o[k].clone() for k in ("box", "refine", "cls", "loc", "mask")})
+    want_box, want_ref = box.clone(), ref.clone()
+    assert m.result_ring_frames(reset=True) == frames
+    box.zero_(); ref.zero_()
+
+    m.set_pipeline(True)
+    got = []
+    for i, x in enumerate(xs):
+        o = m.track_step(x, twh, refine=True, stage=False)
+        # box / cls / loc of THIS frame are complete in stream order; refine / mask behind the join
+        cur = {k: o[k].clone() for k in ("box", "cls", "loc")}
+        m.pipeline_join()
+        cur.update({k: o[k].clone() for k in ("refine", "mask")})
+        got.append(cur)
+    assert m.result_ring_frames() == frames
+    torch.cuda.synchronize()
+    for i in range(frames):
+        for k in ("box", "cls", "loc", "refine", "mask"):
+            assert torch.equal(got[i][k], outs[i][k]), (i, k)
+    assert torch.equal(box, want_box)
+    assert torch.equal(ref, want_ref)
+    g, e = m.seq_status()
+    assert e == 0
+
+    # free-running (no join between steps): the rows must still be the serial rows
+    assert m.result_ring_frames(reset=True) == frames
+    box.zero_(); ref.zero_()
+    for x in xs:
+        m.track_step(x, twh, refine=True, stage=False)
+    assert m.result_ring_frames() == frames
+    assert torch.equal(box, want_box)
+    assert torch.equal(ref, want_ref)
+
+    # serial entry points behind a pipelined step: they join the tail and see that frame's features
+    o = m.track_step(xs[0], twh, refine=True, stage=False)
+    pos = torch.tensor([[12, 12]] * B, dtype=torch.int32).cuda()
+    r1 = m.track_refine(pos).clone()
+    m.set_pipeline(False)
+    m.track_step(xs[0], twh, refine=True, stage=False)
+    r0 = m.track_refine(pos).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(r0, r1)
+
+
+def test_pipelined_200_steps_clean_and_deterministic():
+    """200 free-running pipelined steps at the bench configuration: the persistent sequence never reports a failure (it waits
+    for the tail, so it still owns every CU), the frame counter arrives at 200, and the last rows equal a second run's"""
+    B, rows = 8, 4
+    m = _model(B)
+    z, xs, twh = _inputs(B, 4, 900)
+    m.template(z)
+    box, ref = m.set_result_ring(rows, batch=B)
+    m.set_pipeline(True)
+    snaps = []
+    for rep in range(2):
+        for i in range(200):
+            m.track_step(xs[i % 4], twh, refine=True, stage=False)
+        assert m.result_ring_frames(reset=True) == 200
+        snaps.append((box.clone(), ref.clone()))
+        g, e = m.seq_status()
+        assert g > 0 and e == 0, (g, e)
+    assert torch.equal(snaps[0][0], snaps[1][0]) and torch.equal(snaps[0][1], snaps[1][1])
+    assert m.seq_recovered == 0
+
+
+def test_ring_batch_is_recorded_by_the_library():
+    """a C caller that sets a ring for one batch and steps another one must get SMK_E_ARG, not rows
+    written past the ring"""
+    m = _model(8)
+    z = torch.from_numpy(synth.smooth_image_batch(4, 127, stream0=310)).cuda()
+    m.template(z)
+    box = torch.zeros((2, 2, 8), dtype=torch.float64).cuda()           # sized for batch 2
+    L = _lib.lib()
+    _lib.check(L.smk_set_result_ring(m._ctx, box.data_ptr(), None, 2, 2))
+    x = torch.from_numpy(synth.smooth_image_batch(4, 255, stream0=310)).cuda()
+    twh = torch.tensor([[60.0, 80.0]] * 4, dtype=torch.float64).cuda()
+    cls = torch.empty((4, 10, 25, 25)).cuda(); loc = torch.empty((4, 20, 25, 25)).cuda()
+    b8 = torch.empty((4, 8), dtype=torch.float64).cuda()
+    rc = L.smk_step(m._ctx, x.data_ptr(), 4, _lib.TRACK_MASK | _lib.TRACK_NO_MASK_HEAD, twh.data_ptr(), cls.data_ptr(),
+                    loc.data_ptr(), None, b8.data_ptr(), None, _lib.current_stream_ptr())
+    assert rc == -1 and b"result ring was set for batch 2" in L.smk_last_error()
+    assert L.smk_set_result_ring(m._ctx, box.data_ptr(), None, 2, 9) == -1     # beyond max_batch
+    _lib.check(L.smk_set_result_ring(m._ctx, None, None, 0, 0))
+    torch.cuda.synchronize()
