@@ -345,11 +345,16 @@ def roofline(w, steps=3, mode=2):
         except Exception:  # noqa: BLE001
             pass
     out["rocprofv3"] = rocprof_stats_for(w.name, dom)
-    out["algorithmic_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))
+    # what this figure is: the SUM over the launch's layers of (input + output + weights + residual) -- every inter-layer tensor
+    # counted as if it crossed the fabric.  It is an upper reference, not the floor: for the persistent sequence the floor is
+    # `external_bytes_per_launch` below, and `traffic_over_external` is the honest waste ratio.
+    out["layer_io_bytes_per_launch"] = int(d["bytes"] / max(1, d["calls"]))
     if d.get("ext", 0.0) > 0:
         # conv_seq: the bytes that must cross the fabric when every tensor produced and consumed inside the launch stays in
         # the XCD's L2 (inputs of the sequence, every weight pack once, p2 and the sequence's final output)
         out["external_bytes_per_launch"] = int(d["ext"] / max(1, d["calls"]))
+        if out.get("traffic"):
+            out["traffic_over_external"] = round(out["traffic"] / max(1.0, out["external_bytes_per_launch"]), 2)
     if xc and xc["ms"] > 0:
         out["dw_xcorr"] = {"bound": "hbm", "achieved_GBps": round(xc["bytes"] / (xc["ms"] * 1e-3) / 1e9, 1),
                            "peak_GBps": 8000.0, "frac": round(xc["bytes"] / (xc["ms"] * 1e-3) / 1e9 / 8000.0, 4),

@@ -20,7 +20,14 @@
 extern "C" {
 #endif
 
-/* process-wide tuning knobs for A/B measurements (affect subsequently launched / captured work):
+/* PROCESS-WIDE tuning knobs for A/B measurements (affect subsequently launched / captured work).  They are NOT per context: two
+ * contexts (two models, two dtypes) in one process share them, and a change does not invalidate graphs a context has already
+ * captured.  Product code never calls smk_tune -- every default is the measured choice; tests and tools/measure/ put back what
+ * they change (smk_tune_get).  A per-context copy was considered and left out on purpose: the knobs select between compiled
+ * kernels and launch rules, the contexts hold state (weights, arena, graphs), and nothing on the product path sets one.
+ *   "pipe_join" 0|1 (pipelined frame step, smk_set_pipeline: join with the previous frame's tail by a cross-queue event wait | by the
+ *   in-stream gate kernel (default))   "pipe_eager" bit 0 / 1 (its front / tail as eager launches instead of graphs)
+ *   "wreg96" 0|1 (conv_wreg_kernel: 96 x 256 tiles where 128 x 256 would leave a partial round of workgroups; default 1)
  *   "force_tile" 0 auto | 1 128x128 | 2 128x64 | 3 64x128 | 4 64x64 | 5 256x128   "kt" 0|128|256 (K-tile bytes)
  *   "stages" 0|2|3|4 (LDS ring depth)     "xcd_mode" 0|1|2 (tile -> XCD order)   "min_blocks_x16" (tile thresholds)
  *   "merge" 0|1 (independent convolutions share a launch)   "nt_store" 0|1 (streaming stores of the mask logits)

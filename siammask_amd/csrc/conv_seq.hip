@@ -31,7 +31,9 @@ namespace smk {
 
 #include "wreg_tile.inc"
 #include "c3c1_tile.inc"
-#include "c3c1p_tile.inc"
+#ifdef SMK_MEASURE
+#include "c3c1p_tile.inc"      // (the pair split over two CUs: built, parity-green, a wash -- measurement builds only, see launch_conv_seq)
+#endif
 #include "c3c1s_tile.inc"
 #include "wreg_halo_tile.inc"
 
@@ -63,7 +65,7 @@ __device__ __forceinline__ void team_arrive(unsigned *cnt) {
 
 // One read of a team counter.  spoll: through the SCALAR path (s_load_dword ... glc: misses the scalar cache, served by the XCD's L2,
 // where the arrivals' atomics execute) -- the poll then does not travel the CU's vector memory path, where the workgroup's own requests
-// issued in front of the wait are queued; otherwise a vector sc1 load.  SeqArgs::flags bit 0 (smk_tune "seq_spoll").
+// issued in front of the wait are queued (HISTORY.md 3.1n); otherwise a vector sc1 load.  SeqArgs::flags bit 0 (smk_tune "seq_spoll").
 __device__ __forceinline__ unsigned team_poll(const unsigned *cnt, bool spoll) {
     if (spoll) {
         unsigned v;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
         const int halo_rpt = halo ? (cfg == SEQ_CFG_HALO128 ? 128 : 64) / L.Wo : 1;
         const int halo_tn = (L.Nst + 63) >> 6;
         const int tiles = fused3 ? L.Ho : fused ? (hw + 31) / 32 : (halo ? ((L.Ho + halo_rpt - 1) / halo_rpt) * halo_tn : ((hw + bm - 1) / bm) * tilesN);
+#ifdef SMK_MEASURE
         if (T3 != 0 && fusedp) {
             // pair p = team slots 2p, 2p + 1; 64-row tiles dealt to the pairs (rows per tile evened out when one round covers the
             // image: 961 rows -> 16 tiles of 61); each pair counts its exchanges in bar[8 + p]
@@ -182,7 +185,9 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                         alive = c3c1p_tile<128, 512, 128, CLK>(L, a.L[li + 1], fm0, fme, a.B * hw, hcu, pr, npairs, cnt + 8 + pr, slabs, a, &ctl[2], &ctl[3], smem, tclk, w);
                     }
                 }
-        } else {
+        } else
+#endif
+        {
         const int nk = L.Kpad >> 6;
         // K-loop stagger: the workgroups of a team start at K tiles spread over the whole loop (L.kstag)
         const int kt0 = L.kstag ? (slot * nk) / nslots : 0;
@@ -360,8 +365,14 @@ int launch_conv_seq(const SeqArgs &a_in, int grid, void *stream) {
         triples = triples || cf == SEQ_CFG_C2C3C1_L3 || cf == SEQ_CFG_C2C3C1_L2 || cf == SEQ_CFG_C3C1P_L3 || cf == SEQ_CFG_C3C1P_L2 || cf == 5 || cf == 9;
     }
     if (triples) {
+#ifdef SMK_MEASURE
         if (a.clk || a.clk2) hipLaunchKernelGGL((conv_seq_kernel<4, 1, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_seq_kernel<4, 0, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+#else
+        // triples, the pair split over two CUs, the deep-ring tile and layer1's 128 x 64 tile each measured a wash or a loss
+        // (HISTORY.md 3.1l, 3.1o); the product library does not carry their instantiation (`make MEASURE=1` does)
+        return -5;
+#endif
     } else if (a.clk || a.clk2)                           // SMK_SEQ_CLK=1 / 2: the build with the stamps (eager runs only)
         hipLaunchKernelGGL((conv_seq_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_seq_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);

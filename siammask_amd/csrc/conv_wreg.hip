@@ -106,6 +106,8 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
         if (bn == 256) return launch_wreg_t<2, 4, 1>(cb, stages, s);
         if (bn == 128) return launch_wreg_t<2, 2, 2>(cb, stages, s);
         if (bn == 64) return launch_wreg_t<2, 1, 4>(cb, stages, s);
+    } else if (bm == 96) {
+        if (bn == 256) return launch_wreg_t<3, 4, 1>(cb, stages, s);
     } else if (bm == 128) {
         if (bn == 256) return launch_wreg_t<4, 4, 1>(cb, stages, s);
         if (bn == 128) return launch_wreg_t<4, 2, 2>(cb, stages, s);

@@ -314,6 +314,9 @@ struct smk_ctx {
     hipEvent_t tail_ev = nullptr;
     int ring_batch = 0;              // batch the result ring was sized for (smk_set_result_ring)
     bool pipe_tail_has_mask = false; // (A/B knob pipe_eager bit 1) mid's capture handed the mask head to the tail
+    unsigned *pipe_cnt = nullptr;    // device [2]: tails completed, gates passed (misc_kernels.hip pipe_gate_kernel)
+    unsigned *pipe_sig = nullptr;    // signal memory: main parts completed (pipe_mark_kernel); the tail's hipStreamWaitValue32 target
+    unsigned pipe_sig_n = 0;         // main parts enqueued since the counter was zeroed
 };
 
 static const char *dtname(int dt) { return dt == DT_F16 ? "f16" : "f32"; }
@@ -1141,7 +1144,9 @@ static int seq_health(smk_ctx *c) {
     if (!e) return 0;
     (void)hipDeviceSynchronize();                        // launches that found the flag set returned at once
     c->seq_fail = e;
-    c->seq_grid = 0;
+    if (e != 3) c->seq_grid = 0;                         // (3: the pipelined step's gate timed out -- nothing wrong with the sequences)
+    if (c->pipe_cnt) (void)hipMemset(c->pipe_cnt, 0, 64);
+    if (c->pipe_sig) { (void)hipMemset(c->pipe_sig, 0, 8); c->pipe_sig_n = 0; }
     *(volatile int *)c->seq_err_host = 0;
     (void)hipMemset(c->seq_err, 0, sizeof(int));
     (void)hipMemset(c->seq_bar, 0, 8 * 32 * sizeof(unsigned));
@@ -1153,6 +1158,10 @@ static int seq_health(smk_ctx *c) {
     c->tail_pending = false;                             // (the device has drained)
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
+    if (e == 3)
+        return fail(SMK_E_SEQ, "conv_seq_kernel reported: (pipelined step) the Refine / mask tail of the previous frame did not finish within 0.2 s "
+                    "of the next frame's front end; the results of the calls enqueued on this context since then are invalid (the cached "
+                    "template included): call template() again and re-submit the frame");
     return fail(SMK_E_SEQ, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
                 "(the cached template included); persistent sequences are now off for this context (per-layer kernels from here "
                 "on): call template() again and re-submit the frame",
@@ -1176,7 +1185,7 @@ static bool seq_wanted(const smk_ctx *c, int B) {
 
 // conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
 // (64x256, 64x128, 64x64, 128x256, 128x128, 128x64) or 0.
-static const int WREG_TILE[7][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}};
+static const int WREG_TILE[8][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}, {96, 256}};
 static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (o.algo_naive || !conv_wreg_eligible(p, dtype)) return 0;
     if (o.wreg) return o.wreg;
@@ -1206,7 +1215,16 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
         for (int ci = 0; ci < 4; ++ci) {
             const int bm = WREG_TILE[cand[ci]][0], bn = WREG_TILE[cand[ci]][1];
             if (bn > nr && bn > 64) continue;
-            if ((long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * ng >= 150) return cand[ci];
+            if ((long)((p.M + bm - 1) / bm) * ((p.Nst + bn - 1) / bn) * ng >= 150) {
+                // 128 x 256 with 129 .. 255 workgroups leaves CUs idle for a whole tile time (conv_search at B = 8: 53 x 3 = 159
+                // tiles on 256 CUs); 96 rows (code 7) = 213 tiles, still one round, each 3/4 as long (smk_tune "wreg96", round 5)
+                if (cand[ci] == 4 && g_tune.wreg96) {
+                    const long ncu = 256, tn = (p.Nst + 255) / 256 * ng;
+                    const long t128 = (long)((p.M + 127) / 128) * tn, t96 = (long)((p.M + 95) / 96) * tn;
+                    if (((t128 + ncu - 1) / ncu) * 128 > ((t96 + ncu - 1) / ncu) * 96 && t96 <= 4 * ncu) return 7;
+                }
+                return cand[ci];
+            }
         }
         return 3;
     }
@@ -2005,6 +2023,8 @@ int smk_destroy(smk_ctx *c) {
     for (int i = 0; i < 2; ++i) if (c->side[i]) hipStreamDestroy(c->side[i]);
     for (auto &e : c->pipe_ev) hipEventDestroy(e);
     if (c->pipe_stream) hipStreamDestroy(c->pipe_stream);
+    if (c->pipe_cnt) hipFree(c->pipe_cnt);
+    if (c->pipe_sig) hipFree(c->pipe_sig);
     delete c;
     return 0;
 }
@@ -2168,7 +2188,7 @@ int smk_seq_status(smk_ctx *c, int *grid, int *err) {
     if (grid) *grid = c->seq_grid;
     if (err) *err = c->seq_fail;
     if (rc) return rc;
-    if (c->seq_fail)
+    if (c->seq_fail && c->seq_fail != 3)
         return fail(SMK_E_STATE, "conv_seq_kernel reported %s earlier; persistent sequences are off for this context",
                     c->seq_fail == 1 ? "an uneven distribution of workgroups over the XCDs" : "a team-barrier time-out");
     return 0;
@@ -2263,7 +2283,13 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "merge_max_batch")) g_tune.merge_max_batch = value;
     else if (!strcmp(key, "seq_spoll")) g_tune.seq_spoll = value != 0;
     else if (!strcmp(key, "rf_wreg")) g_tune.rf_wreg = value;
-    else if (!strcmp(key, "seq_fuse3")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_fuse3 0..2"); g_tune.seq_fuse3 = value; }
+    else if (!strcmp(key, "seq_fuse3")) {
+        if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_fuse3 0..2");
+#ifndef SMK_MEASURE
+        if (value) return fail(SMK_E_ARG, "seq_fuse3: the triple routine (measured a wash) is only in a library built with `make MEASURE=1`");
+#endif
+        g_tune.seq_fuse3 = value;
+    }
     else if (!strcmp(key, "nchw_tn_major")) g_tune.nchw_tn_major = value != 0;
     else if (!strcmp(key, "chain_mask")) g_tune.chain_mask = value != 0;
     else if (!strcmp(key, "wreg")) { if (value < 0 || value > 7) return fail(SMK_E_ARG, "wreg 0..7"); g_tune.wreg = value; }
@@ -2276,18 +2302,35 @@ int smk_tune(const char *key, int value) {
 #endif
     }
     else if (!strcmp(key, "seq_kstag")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_kstag 0|1|2"); g_tune.seq_kstag = value; }
-    else if (!strcmp(key, "seq_deep")) g_tune.seq_deep = value != 0;
+    else if (!strcmp(key, "seq_deep")) {
+#ifndef SMK_MEASURE
+        if (value) return fail(SMK_E_ARG, "seq_deep: the deep-ring measurement tile is only in a library built with `make MEASURE=1`");
+#endif
+        g_tune.seq_deep = value != 0;
+    }
     else if (!strcmp(key, "corr_head")) g_tune.corr_head = value != 0;
     else if (!strcmp(key, "pair_launch")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "pair_launch 0..3"); g_tune.pair_launch = value; }
     else if (!strcmp(key, "rf_tile2")) { if (value < 0 || value > 5) return fail(SMK_E_ARG, "rf_tile2 0..5"); g_tune.rf_tile2 = value; }
-    else if (!strcmp(key, "seq_pair2d")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2"); g_tune.seq_pair2d = value; }
+    else if (!strcmp(key, "seq_pair2d")) {
+        if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_pair2d 0..2");
+#ifndef SMK_MEASURE
+        if (value) return fail(SMK_E_ARG, "seq_pair2d: the pair split over two CUs (measured a wash) is only in a library built with `make MEASURE=1`");
+#endif
+        g_tune.seq_pair2d = value;
+    }
     else if (!strcmp(key, "seq_fuse")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_fuse 0..3"); g_tune.seq_fuse = value; }
     else if (!strcmp(key, "seq_ds128")) g_tune.seq_ds128 = value != 0;
     else if (!strcmp(key, "seq_halo")) g_tune.seq_halo = value != 0;
     else if (!strcmp(key, "seq_kstag_mask")) g_tune.seq_kstag_mask = value & 7;
     else if (!strcmp(key, "res_nt")) g_tune.res_nt = value != 0;
     else if (!strcmp(key, "seq_tall")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "seq_tall 0|1|2"); g_tune.seq_tall = value; }
-    else if (!strcmp(key, "seq_first_stage")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3"); g_tune.seq_first_stage = value; }
+    else if (!strcmp(key, "seq_first_stage")) {
+        if (value < 0 || value > 3) return fail(SMK_E_ARG, "seq_first_stage 0..3");
+#ifndef SMK_MEASURE
+        if (value == 0) return fail(SMK_E_ARG, "seq_first_stage 0 (layer1 inside the sequence: measured 140 us against 96) is only in a library built with `make MEASURE=1`");
+#endif
+        g_tune.seq_first_stage = value;
+    }
     else if (!strcmp(key, "seq_min_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_min_batch >= 1"); g_tune.seq_min_batch = value; }
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
     else if (!strcmp(key, "seq_extra_batch")) g_tune.seq_extra_batch = value;
@@ -2307,6 +2350,9 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
     else if (!strcmp(key, "pipe_eager")) g_tune.pipe_eager = value & 3;
+    else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
+    else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
@@ -2334,7 +2380,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2494,13 +2540,15 @@ static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *ref
     return 0;
 }
 
-// Pipelined frame step (smk_set_pipeline(ctx, 1)): three linear graphs and two events per frame --
-//   caller's stream:  front(f) = stem + layer1 into copy f % 2 of p0 / p1 | wait tail(f-1) | mid(f) = layer2 .. decode
-//   side stream:      wait mid(f) | tail(f) = Refine (+ mask head) at the decoded positions
-// tail(f) (small launches, low occupancy) shares the chip with front(f+1) (bandwidth-bound); the persistent layer2 .. adjust launch of
-// frame f + 1 waits for tail(f) so that it still owns every CU.  front(f+1) is ordered behind decode(f) by the caller's stream, as a
-// tracker that crops frame f + 1 at the decoded box needs it.  Everything both sides touch is either written by mid (after the wait)
-// or exists twice (p0, p1).
+// Pipelined frame step (smk_set_pipeline(ctx, 1)): two linear graphs per frame --
+//   caller's stream:  main(f) = stem + layer1 into copy f % 2 of p0 / p1 | gate: wait for tail(f-1) | layer2 .. heads .. decode
+//   side stream:      wait (event) for main(f) | tail(f) = Refine (+ mask head) at the decoded positions | completion mark
+// tail(f) (small launches, low occupancy) shares the chip with the front end of frame f + 1 (bandwidth-bound); the persistent
+// layer2 .. adjust launch of frame f + 1 sits behind the gate so that it still owns every CU.  The front end of f + 1 is ordered behind
+// decode(f) by the caller's stream, as a tracker that crops frame f + 1 at the decoded box needs it.  Everything both sides touch is
+// either written behind the gate or exists twice (p0, p1).  The join is an in-stream gate kernel (misc_kernels.hip pipe_gate_kernel),
+// not an event: a cross-queue event wait on the critical path costs 15-22 us here (smk_tune "pipe_join" = 0 keeps that form --
+// three graphs, front | event wait | mid -- for the A/B).
 static int step_pipelined(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
                           float *mask, double *box_out, float *refine_out, hipStream_t s) {
     const int par = c->pipe_parity;
@@ -2508,30 +2556,67 @@ static int step_pipelined(smk_ctx *c, const float *x, int B, int flags, const do
     int64_t pk, wi;
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     const std::vector<const void *> io{x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi};
-    const GraphKey kf{10, B, flags | (par << 16), io}, km{11, B, flags | (par << 16), io}, kt{12, B, flags | (par << 16), io};
+    const bool gate = g_tune.pipe_join != 0;
+    const bool sig = gate && g_tune.pipe_sig == 1 && c->pipe_sig;
+    const bool tgate = gate && g_tune.pipe_sig == 2;      // the tail's start is a gate kernel too (A/B)
+    const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0);
+    const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io};
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
-    auto tail = [&](hipStream_t st) { return step_tail(c, B, mask, box_out, refine_out, st); };
+    auto main_ = [&](hipStream_t st) {
+        CHK(front(st));
+        if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        c->cap_has_seq = true;              // (the gate reports through the sequence failure flag: checked like a sequence launch)
+        CHK(mid(st));
+        if (sig && launch_pipe_mark(c->pipe_sig, st)) return fail(SMK_E_HIP, "pipe_mark launch failed");
+        if (tgate && launch_pipe_mark(c->pipe_cnt + 2, st)) return fail(SMK_E_HIP, "pipe_mark launch failed");
+        return 0;
+    };
+    auto tail = [&](hipStream_t st) {
+        if (tgate && launch_pipe_tail_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_tail_gate launch failed");
+        CHK(step_tail(c, B, mask, box_out, refine_out, st));
+        if (gate && launch_pipe_done(c->pipe_cnt, st)) return fail(SMK_E_HIP, "pipe_done launch failed");
+        return 0;
+    };
     const bool graphs = c->graph_mode;
-    if (graphs && !(c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt))) {
-        // the three are captured together: mid hands the mask head over to tail at capture time
+    const bool have = gate ? (c->graphs.count(km) && c->graphs.count(kt)) : (c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt));
+    if (graphs && !have) {
+        // captured together: the middle part hands the mask head over to the tail at capture time
         drop_graph(c, kf); drop_graph(c, km); drop_graph(c, kt);
-        CHK(capture_graph(c, kf, front));
-        CHK(capture_graph(c, km, mid));
+        if (gate) CHK(capture_graph(c, km, main_));
+        else { CHK(capture_graph(c, kf, front)); CHK(capture_graph(c, km, mid)); }
         c->pipe_tail_has_mask = c->have_deferred_mask;
         CHK(capture_graph(c, kt, tail));
-        if (!(c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt))) return fail(SMK_E_STATE, "internal: pipelined step graphs evicted while capturing");
+        if (!(c->graphs.count(km) && c->graphs.count(kt))) return fail(SMK_E_STATE, "internal: pipelined step graphs evicted while capturing");
     }
-    CHK((graphs && !(g_tune.pipe_eager & 1)) ? launch_graph(c, kf, s) : front(s));
-    CHK(pipe_join(c, s, true));
-    CHK(graphs ? launch_graph(c, km, s) : mid(s));
+    if (gate) {
+        CHK(graphs ? launch_graph(c, km, s) : main_(s));
+        if (!graphs) c->seq_pending = true;
+        // (no event wait on `s`: the gate inside main(f) is the join; tail_ev stays for the serial entry points and smk_pipeline_join)
+        c->tail_pending = false;
+    } else {
+        CHK((graphs && !(g_tune.pipe_eager & 1)) ? launch_graph(c, kf, s) : front(s));
+        CHK(pipe_join(c, s, true));
+        CHK(graphs ? launch_graph(c, km, s) : mid(s));
+    }
     hipEvent_t e_dec = c->pipe_ev[c->pipe_ev_next++ % c->pipe_ev.size()];
     hipEvent_t e_tail = c->pipe_ev[c->pipe_ev_next++ % c->pipe_ev.size()];
-    HIPCHK(hipEventRecord(e_dec, s));
-    HIPCHK(hipStreamWaitEvent(c->pipe_stream, e_dec, 0));
+    if (sig) {
+        // the side stream's command processor polls the counter the main graph's last kernel advances: nothing is enqueued on `s`
+        if (c->pipe_sig_n >= 0x7fff0000u) {                   // (every 2^31 frames: start the count over)
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemset(c->pipe_sig, 0, 8));
+            c->pipe_sig_n = 0;
+            return fail(SMK_E_STATE, "internal: pipelined frame counter wrapped; re-submit the frame");
+        }
+        HIPCHK(hipStreamWaitValue32(c->pipe_stream, c->pipe_sig, ++c->pipe_sig_n, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    } else if (!tgate) {
+        HIPCHK(hipEventRecord(e_dec, s));
+        HIPCHK(hipStreamWaitEvent(c->pipe_stream, e_dec, 0));
+    }
     if (graphs && !(g_tune.pipe_eager & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
     else {
-        // (eager: mid's capture-time hand-over of the mask head is replayed from the context, see step_track_decode)
+        // (eager: the capture-time hand-over of the mask head is replayed from the context, see step_track_decode)
         if (graphs) c->have_deferred_mask = c->pipe_tail_has_mask;
         CHK(tail(c->pipe_stream));
     }
@@ -2592,6 +2677,15 @@ int smk_set_pipeline(smk_ctx *c, int depth) {
             CHK(alloc_buf(c, "p1#1", c->buf_elems.at("p1")));
         }
         if (!c->pipe_stream) HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+        if (!c->pipe_cnt) HIPCHK(hipMalloc((void **)&c->pipe_cnt, 64));
+        HIPCHK(hipMemset(c->pipe_cnt, 0, 64));                  // tails completed = gates passed = 0
+        if (!c->pipe_sig) {
+            int can = 0;
+            (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+            if (can && hipExtMallocWithFlags((void **)&c->pipe_sig, 8, hipMallocSignalMemory) != hipSuccess) { c->pipe_sig = nullptr; (void)hipGetLastError(); }
+        }
+        if (c->pipe_sig) HIPCHK(hipMemset(c->pipe_sig, 0, 8));
+        c->pipe_sig_n = 0;
         if (c->pipe_ev.empty()) {
             c->pipe_ev.resize(16);
             for (auto &e : c->pipe_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

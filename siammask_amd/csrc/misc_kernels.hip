@@ -624,6 +624,71 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
     }
 }
 
+// ---- pipelined frame steps (smk_set_pipeline): the in-stream join with the side stream's Refine / mask tail -----------------
+// A cross-queue event wait costs 15-22 us on this platform (measured: profiles/r05a_pipelined_timeline.txt), more than half of what
+// the overlap saves.  The join is therefore a one-wave GATE kernel in the step's own stream: it polls a device counter that a
+// one-thread kernel at the end of the tail advances.  cnt[0] = tails completed, cnt[1] = gates passed: gate number g (0, 1, ...) lets
+// its stream continue once g tails have completed, i.e. it waits for the tail of the previous frame; baked launch arguments, so it
+// replays from a captured graph.  While it polls, every CU but the gate's wave slot is free for the tail (the front end in front of
+// the gate has drained: same stream), and the tail never waits for anything behind the gate -- no deadlock.  A tail that does not
+// arrive within 0.2 s raises the sequence failure flag (code 3): the caller re-submits, as for a barrier time-out.
+__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *cnt, int *err, int *err_host) {
+    if (threadIdx.x != 0) return;
+    const unsigned want = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {          // 100 MHz: 0.2 s
+            __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __hip_atomic_store(cnt + 1, want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *cnt) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the main part's completion mark for the side stream: the tail's start is a hipStreamWaitValue32 on this counter (signal memory;
+// 3-4 us from the write to the waiter's first instruction, tools/order_probe.hip) instead of an event record in the step's own
+// stream (4-8 us in front of the next frame's first kernel) plus a cross-queue event wait (10-12 us)
+__global__ __launch_bounds__(64) void pipe_mark_kernel(unsigned *sig) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// smk_tune pipe_sig = 2: the tail's START is a gate as well -- one wave at the head of the tail graph polls the counter MARK advances
+// (cnt[2] = main parts completed, cnt[3] = tail gates passed).  It becomes resident as soon as the previous tail has drained, i.e. it
+// polls THROUGH the next frame's persistent launch and must fit beside a conv_seq_kernel workgroup (one wave, < 16 VGPRs, no LDS).
+__global__ __launch_bounds__(64) void pipe_tail_gate_kernel(unsigned *cnt, int *err, int *err_host) {
+    if (threadIdx.x != 0) return;
+    const unsigned want = __hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(cnt + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
+            __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __hip_atomic_store(cnt + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+int launch_pipe_tail_gate(unsigned *cnt, int *err, int *err_host, void *stream) {
+    hipLaunchKernelGGL(pipe_tail_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt, err, err_host);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_pipe_mark(unsigned *sig, void *stream) {
+    hipLaunchKernelGGL(pipe_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sig);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_pipe_gate(unsigned *cnt, int *err, int *err_host, void *stream) {
+    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt, err, err_host);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_pipe_done(unsigned *cnt, void *stream) {
+    hipLaunchKernelGGL(pipe_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_ring_commit(const RingParams &p, void *stream) {
     if (!p.cursor || !p.done || p.rows < 1 || p.B < 1) return -1;
     const size_t nref = (size_t)p.B * p.n;

@@ -213,6 +213,13 @@ struct Tuning {
                                // waves), 1 = the rule fitted with four (wreg_choice)
     int npw = 4;               // conv_wreg / conv_seq: producer waves per workgroup (2 or 4; measured: profiles/r02_producer_waves_2_vs_4.txt)
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
+    int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
+    int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
+                               // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
+    int pipe_sig = 0;          // pipelined frame step, A/B knob: 1 = the tail's start waits for a counter in signal memory (hipStreamWaitValue32) that a
+                               // one-thread kernel behind decode advances -- 3-4 us in the two-kernel probe (tools/order_probe.hip) but 0.85 ms per step
+                               // against 0.557 in the real loop (profiles/r05e_pipe_sig_ab.txt: a queue parked on a wait-value stalls the other queue's
+                               // dispatches); 0 (default) = hipEventRecord in the step's stream + hipStreamWaitEvent
     int pipe_eager = 0;        // pipelined frame step, A/B knob: bit 0 = the front end (stem + layer1) as eager launches instead of a graph,
                                // bit 1 = the Refine / mask tail as eager launches
 };
@@ -420,6 +427,11 @@ int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
 int launch_ring_commit(const RingParams &p, void *stream);
+// pipelined frame steps: in-stream gate (waits for the previous frame's tail) / the tail's completion mark; cnt = device [2] u32
+int launch_pipe_gate(unsigned *cnt, int *err, int *err_host, void *stream);
+int launch_pipe_done(unsigned *cnt, void *stream);
+int launch_pipe_tail_gate(unsigned *cnt, int *err, int *err_host, void *stream);     // (smk_tune pipe_sig = 2)
+int launch_pipe_mark(unsigned *sig, void *stream);          // sig: signal memory (hipMallocSignalMemory), waited for with hipStreamWaitValue32
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);
 int launch_paste_labels(const PasteParams &p, int n_obj, void *stream);

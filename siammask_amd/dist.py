@@ -50,9 +50,10 @@ def gpu_numa_node(pci_bus_id, sysfs="/sys"):
 def rank_cpus(local_rank, n_local, pci_bus_id=None, allowed=None, sysfs="/sys"):
     """The CPUs a rank should run on.  The reference's scale-out is one process per GPU too (experiments/siammask_sharp/
     test_all.sh:68,77) and leaves placement to the OS; on an 8-GPU node with 2 sockets that lets a rank's host thread -- which
-    enqueues a graph every 0.6 ms -- run a socket away from its GPU.  Rule: the CPUs of the GPU's NUMA node (sysfs), split
-    evenly among the local ranks that share that node when several do (their order is their local rank); without NUMA
-    information an even contiguous share of the allowed CPUs.  Never returns an empty set."""
+    enqueues a graph every 0.6 ms -- run a socket away from its GPU.  Rule: ALL the CPUs of the GPU's NUMA node (sysfs) that the
+    process is allowed on -- ranks that share a node share its CPUs (a rank has one busy host thread; the OS spreads them inside
+    the node); without NUMA information an even contiguous share of the allowed CPUs, the remainder going to the last rank.
+    Never returns an empty set."""
     allowed = set(allowed if allowed is not None else os.sched_getaffinity(0))
     node = gpu_numa_node(pci_bus_id, sysfs) if pci_bus_id else -1
     if node >= 0:
@@ -64,13 +65,20 @@ def rank_cpus(local_rank, n_local, pci_bus_id=None, allowed=None, sysfs="/sys"):
         except OSError:
             pass
     order = sorted(allowed)
-    share = max(1, len(order) // max(1, n_local))
-    lo = (local_rank % max(1, n_local)) * share
-    return set(order[lo:lo + share]) or set(order), -1
+    n = max(1, n_local)
+    share = max(1, len(order) // n)
+    r = local_rank % n
+    lo = r * share
+    hi = len(order) if r == n - 1 else lo + share          # (the tail CPUs of an uneven split belong to the last rank)
+    return set(order[lo:hi]) or set(order), -1
 
 
 def pin_rank(local_rank, n_local, device_index=None):
-    """Apply rank_cpus() to this process (SMK_NO_AFFINITY=1 leaves placement alone).  -> dict for the dry-run report."""
+    """Apply rank_cpus() to the CALLING THREAD (os.sched_setaffinity(0, ...) is per thread on Linux; SMK_NO_AFFINITY=1 leaves
+    placement alone).  Threads created afterwards inherit it; helper threads the HIP runtime / RCCL started before the call keep
+    theirs -- call this before the first CUDA call where that matters (bench.py pins right after torch.cuda.set_device, i.e. the
+    runtime's own early threads are not covered; the report's "pinned" says exactly: the enqueueing thread is).
+    -> dict for the dry-run report."""
     bdf = None
     if device_index is not None and torch.cuda.is_available():
         try:
@@ -86,7 +94,8 @@ def pin_rank(local_rank, n_local, device_index=None):
             pinned = True
         except OSError:
             pinned = False
-    return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "cpu_first": min(cpus), "cpu_last": max(cpus), "pinned": pinned}
+    return {"pci": bdf, "numa_node": node, "cpus": len(cpus), "cpu_first": min(cpus), "cpu_last": max(cpus), "pinned": pinned,
+            "pinned_scope": "calling thread + threads created after the call"}
 
 
 def shard_streams(n_streams, rank, world):

@@ -87,6 +87,17 @@ def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
     assert torch.equal(r0, r1)
 
 
+def test_event_join_form_is_the_same_arithmetic():
+    """smk_tune pipe_join = 0: the first form of the pipeline (three graphs, cross-queue event wait instead of the in-stream gate
+    kernel) -- kept for the A/B; same rows"""
+    old = _lib.tune_get("pipe_join")
+    try:
+        _lib.tune(pipe_join=0)
+        test_pipelined_rows_equal_serial_rows(8, "f16", 5)
+    finally:
+        _lib.tune(pipe_join=old)
+
+
 def test_pipelined_200_steps_clean_and_deterministic():
     """200 free-running pipelined steps at the bench configuration: the persistent sequence never reports a failure (it waits
     for the tail, so it still owns every CU), the frame counter arrives at 200, and the last rows equal a second run's"""

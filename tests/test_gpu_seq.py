@@ -69,6 +69,8 @@ def _bottleneck(rng, cin, planes, k2=3, dil=2, tile=None, kstag=-1):
 def test_conv_seq_every_tile_configuration(tile, kstag):
     """a Bottleneck (1x1 -> dilated 3x3 -> 1x1 + residual) forced onto each workgroup tile; B = 3 (three teams work, five
     idle through every barrier), 23x23 = 529 rows per image: ragged last tile for 64- and 128-row tiles"""
+    if tile == (128, 64) or tile == "deep":
+        _needs_measure_build("the %s sequence tile (layer1 inside a sequence / the deep-ring measurement variant)" % (tile,))
     ops = _ops()
     rng = np.random.default_rng(11 + TILES.index(tile) + 100 * kstag)
     x = rng.uniform(-1, 1, size=(3, 256, 23, 23)).astype(np.float32)
@@ -215,6 +217,15 @@ def test_conv_seq_fused_conv3_conv1_pairs(shape, B, S):
         assert rel_err(outs[i].cpu().numpy(), plain[i].cpu().numpy().astype(np.float64)) <= 1e-3, i
 
 
+def _needs_measure_build(what):
+    """round 5: the arms that measured a wash (pair split over two CUs, triples) left the product library; they are compiled by
+    `make MEASURE=1` only (HISTORY.md 3.1l, 3.1o) -- their parity tests run against such a build and are skipped otherwise"""
+    from siammask_amd import _lib
+    if not _lib.tune_get("measure_build"):
+        pytest.skip("%s is only in a library built with `make MEASURE=1`" % what)
+
+
+
 @pytest.mark.parametrize("shape", [(1024, 256), (512, 128)])
 @pytest.mark.parametrize("B,S", [(3, 23), (8, 31), (10, 15), (8, 47)])
 def test_conv_seq_pair_split_over_two_cus(shape, B, S):
@@ -224,6 +235,7 @@ def test_conv_seq_pair_split_over_two_cus(shape, B, S):
     two images on two of the teams (B = 10: consecutive exchanges of a pair, both slab sets), several rounds of tiles per pair
     (47 x 47 = 2209 rows -> 35 tiles of 64 on 16 pairs: the last round has idle pairs).  Both outputs of the pair one layer deep;
     against the one-CU routine: conv1 / conv2 bit-equal, the pair within summation-order noise; 5 launches bit-identical."""
+    _needs_measure_build("the pair split over two CUs (seq_pair2d)")
     from siammask_amd import _lib
     ops = _ops()
     cin, planes = shape
@@ -259,6 +271,7 @@ def test_conv_seq_pair_split_chain_of_layer3_blocks_and_adjust():
     """three identity Bottlenecks of layer3 + adjust at the bench's batch with every pair split over two CUs: three exchanges per
     pair and launch (slab sets 0, 1, 0), each pair's residual is the previous pair's conv3 output (written in two channel halves
     by two CUs)"""
+    _needs_measure_build("the pair split over two CUs (seq_pair2d)")
     from siammask_amd import _lib
     ops = _ops()
     rng = np.random.default_rng(181)
@@ -532,6 +545,7 @@ def test_conv_seq_fused_triples(shape, dil, B, S):
     the previous triple's conv3 output written by the SAME workgroup; dilation 1 and 2 (33 / 35-pixel padded rows), both layers'
     shapes, idle teams (B = 3), two images on two of the teams (B = 10), 29-pixel rows.  Against the unfused list (itself held to the
     oracle one layer deep): conv3's and the 1x1's outputs within fp16 summation-order noise; run twice: bit-identical."""
+    _needs_measure_build("the triple routine (seq_fuse3)")
     from siammask_amd import _lib
     ops = _ops()
     cin, planes = shape
@@ -562,6 +576,7 @@ def test_conv_seq_fused_triples(shape, dil, B, S):
 def test_conv_seq_triples_leave_short_rows_and_shared_conv2_outputs_alone():
     """the template's 15 x 15 images keep the pairs (one image row would fill half a tile), and a conv2 whose output somebody else
     reads as well must reach memory: no triple"""
+    _needs_measure_build("the triple routine (seq_fuse3)")
     from siammask_amd import _lib
     ops = _ops()
     rng = np.random.default_rng(151)

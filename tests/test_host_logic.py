@@ -223,7 +223,8 @@ def test_layer_rules_are_the_measured_ones():
     assert _plan(8, 128, 31, 128, 3, pad=1)[2] == 25                           # l2.c2   64 pixels (2 whole rows) x 64, patch shared
     assert _plan(8, 128, 31, 512, 1, res=True)[2] == 0                         # l2.c3   64x256
     # B = 8 per launch
-    assert _plan(8, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))               # conv_search (N-fused 768)
+    assert _plan(8, 256, 31, 768, 3)[:2] == ("wreg", (96, 256))                # conv_search (N-fused 768): 213 tiles of 96 rows = ONE round (128 rows: 159 tiles
+                                                                               # on 256 CUs, each a third longer; round 5, profiles/r05d_wreg96_ab.txt)
     assert _plan(8, 64, 63, 64, 3, pad=1)[0] == "halo"                         # l1.c2: short-K 3x3 stays on the patch kernel
     assert _plan(8, 64, 63, 256, 1, res=True)[:2] == ("igemm", (128, 128))     # l1.c3: large M, short K
     assert _plan(8, 256, 63, 64, 1)[0] == "igemm"                              # l1.c1

@@ -34,7 +34,8 @@ def collect(B=64, seeds=8, kinds=("smooth", "noise"), variant="sharp", host_psco
     from siammask_amd import synth
     m16, m32 = models or (_model(variant, "f16", B), _model(variant, "f32", B))
     gen = {"smooth": synth.smooth_image_batch, "noise": synth.image_batch}
-    out = {"streams": 0, "agree": 0, "per_kind": {}, "mismatches": [], "batch": B, "seeds": seeds, "variant": variant}
+    out = {"streams": 0, "agree": 0, "per_kind": {}, "mismatches": [], "batch": B, "seeds": seeds, "variant": variant,
+           "best16": {}, "best32": {}}          # per kind: [seeds][B] device best_id of each context (the fp64-oracle comparison of the test)
     for kind in kinds:
         pk = out["per_kind"].setdefault(kind, {"streams": 0, "agree": 0})
         for seed in range(seeds):
@@ -51,6 +52,8 @@ def collect(B=64, seeds=8, kinds=("smooth", "noise"), variant="sharp", host_psco
                 res.append({k: o[k].cpu().numpy() for k in ("box", "cls", "loc")})
             torch.cuda.synchronize()
             b16, b32 = res[0]["box"][:, 7].astype(np.int64), res[1]["box"][:, 7].astype(np.int64)
+            out["best16"].setdefault(kind, []).append(b16)
+            out["best32"].setdefault(kind, []).append(b32)
             same = b16 == b32
             out["streams"] += B; out["agree"] += int(same.sum())
             pk["streams"] += B; pk["agree"] += int(same.sum())

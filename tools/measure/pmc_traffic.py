@@ -29,23 +29,29 @@ if not (0.3 < WR < 2.5):
 CONV = ("conv_igemm_kernel", "conv3x3_halo_kernel", "conv_wreg_kernel", "conv_seq_kernel")
 per = {}
 tot = {"launches": 0, "fetch": 0.0, "write": 0.0}
+def per_launch(c, name, default=0.0):
+    """a counter's value PER LAUNCH with the counter's OWN dispatch count: the passes do not see the same number of dispatches
+    (a timed-out pass, a warm-up launch more or less), so dividing one pass's sum by another pass's count is wrong -- round 4's
+    per_instantiation table divided the WRITE_SIZE / TCC sums (407 dispatches) by the FETCH pass's 327"""
+    v = c.get(name)
+    return v["sum"] / max(1, v["dispatches"]) if v else default
+
+
 for k, c in d.items():
-    if not any(s in k for s in CONV) or "FETCH_SIZE" not in c:
+    if not any(s in k for s in CONV) or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
     n = c["FETCH_SIZE"]["dispatches"]
-    f, w = c["FETCH_SIZE"]["sum"], c["WRITE_SIZE"]["sum"]
-    hit, req = c.get("TCC_HIT_sum", {"sum": 0})["sum"], c.get("TCC_REQ_sum", {"sum": 1})["sum"]
-    gui = c.get("GRBM_GUI_ACTIVE", {"sum": 0, "dispatches": 1})
-    mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", {"sum": 0, "dispatches": 1})
-    per[k] = {"dispatches": n, "fetch_kb_per_launch": round(f / n, 1), "write_kb_per_launch": round(w / n, 1),
-              "hbm_bytes_per_launch_corrected": int((f / FR + w / WR) / n * 1024),
-              "tcc_hit_rate": round(hit / max(1.0, req), 3),
+    f, w = per_launch(c, "FETCH_SIZE"), per_launch(c, "WRITE_SIZE")          # KB per launch, each by its own pass's count
+    per[k] = {"dispatches": {x: c[x]["dispatches"] for x in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_REQ_sum") if x in c},
+              "fetch_kb_per_launch": round(f, 1), "write_kb_per_launch": round(w, 1),
+              "hbm_bytes_per_launch_corrected": int((f / FR + w / WR) * 1024),
+              "tcc_hit_rate": round(per_launch(c, "TCC_HIT_sum") / max(1.0, per_launch(c, "TCC_REQ_sum", 1.0)), 3),
               # matrix-pipe busy cycles per SIMD / shader cycles of the kernel (GRBM_GUI_ACTIVE counts every XCD: / 8); both per
               # (pass, dispatch) instance -- pmc_stats.py counts GUI_ACTIVE's instances over all the passes it rides in
-              "mfma_util_est": round((mf["sum"] / max(1, mf["dispatches"]) / 1024.0) /
-                                     (gui["sum"] / max(1, gui["dispatches"]) / 8.0 + 1e-9), 3),
-              "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT", {"sum": 0})["sum"]}
-    tot["launches"] += n; tot["fetch"] += f; tot["write"] += w
+              "mfma_util_est": round((per_launch(c, "SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0) / (per_launch(c, "GRBM_GUI_ACTIVE") / 8.0 + 1e-9), 3),
+              "lds_bank_conflict_per_launch": round(per_launch(c, "SQ_LDS_BANK_CONFLICT"), 1)}
+    # family totals: per-launch figures weighted by the FETCH pass's launch count
+    tot["launches"] += n; tot["fetch"] += f * n; tot["write"] += w * n
 def one(name):
     for k, c in d.items():
         if name in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
