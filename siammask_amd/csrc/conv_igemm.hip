@@ -988,12 +988,25 @@ __global__ __launch_bounds__(1024) void chain_mask_kernel(const RefineChainParam
     __shared__ __attribute__((aligned(16))) unsigned char smem[CM_LDS];
     if ((int)blockIdx.x < rp.B) {
         refine_chain_body<false>(rp, (int)blockIdx.x, smem);
-        return;
+    } else {
+        const int half = threadIdx.x >> 9;
+        const int bx = 2 * ((int)blockIdx.x - rp.B) + half;
+        if (bx < cb.start[cb.n])                       // (odd tile count -- refused by the launcher: the last workgroup would run one tile)
+            conv_igemm_body<_Float16, 2, 2, 1, 128, OUT_NCHW_F32, 2>(cb, bx, 0, half * 512, smem + half * CM_CONV_LDS);
     }
-    const int half = threadIdx.x >> 9;
-    const int bx = 2 * ((int)blockIdx.x - rp.B) + half;
-    if (bx >= cb.start[cb.n]) return;                  // odd tile count: the last workgroup runs one tile
-    conv_igemm_body<_Float16, 2, 2, 1, 128, OUT_NCHW_F32, 2>(cb, bx, 0, half * 512, smem + half * CM_CONV_LDS);
+    if (rp.tail_sem) {
+        // pipelined frame step: this launch ends the tail -- the last workgroup to get here lets the next frame's persistent launch
+        // through its gate (semaphore V, misc_kernels.hip) instead of a one-thread kernel behind this one.  Only CU ownership hangs
+        // on it (every workgroup has issued its last instruction but the exit); the outputs become visible at the launch's end as always.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(rp.tail_sem + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {
+                __hip_atomic_store(rp.tail_sem + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(rp.tail_sem, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // cb: ONE f16 problem with the NCHW f32 epilogue (the mask head), 128x128 tiles

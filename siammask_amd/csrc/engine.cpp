@@ -314,7 +314,10 @@ struct smk_ctx {
     hipEvent_t tail_ev = nullptr;
     int ring_batch = 0;              // batch the result ring was sized for (smk_set_result_ring)
     bool pipe_tail_has_mask = false; // (A/B knob pipe_eager bit 1) mid's capture handed the mask head to the tail
-    unsigned *pipe_cnt = nullptr;    // device [2]: tails completed, gates passed (misc_kernels.hip pipe_gate_kernel)
+    unsigned *pipe_cnt = nullptr;    // device [16] u32: [0] semaphore "tails completed" (starts at 1), [2] semaphore "main parts completed",
+                                     // [4] / [5] arrival counters of decode's streams / chain_mask's workgroups (misc_kernels.hip pipe_*)
+    bool pipe_gate_late = false;     // (recording a pipelined step) seq_track launches the main gate in front of the heads
+    bool pipe_mark_fold = false, pipe_tail_fold = false, pipe_done_folded = false;   // (while a pipelined step's parts are being recorded)
     unsigned *pipe_sig = nullptr;    // signal memory: main parts completed (pipe_mark_kernel); the tail's hipStreamWaitValue32 target
     unsigned pipe_sig_n = 0;         // main parts enqueued since the counter was zeroed
 };
@@ -627,7 +630,8 @@ static int build_arena(smk_ctx *c) {
 static Act act(smk_ctx *c, const char *name, int H, int W, int C) {
     Act a;
     // p0 / p1 exist twice while frame steps are pipelined (the tail of frame f reads one copy, the front of f + 1 writes the other)
-    if (c->parity_now && name[0] == 'p' && (name[1] == '0' || name[1] == '1') && !name[2]) a.p = c->buf.at(name[1] == '0' ? "p0#1" : "p1#1");
+    if (c->parity_now && name[0] == 'p' && (name[1] == '0' || name[1] == '1' || name[1] == '2') && !name[2])
+        a.p = c->buf.at(name[1] == '0' ? "p0#1" : (name[1] == '1' ? "p1#1" : "p2#1"));
     else
     a.p = c->buf.at(name);
     a.H = H; a.W = W; a.C = C;
@@ -1145,7 +1149,10 @@ static int seq_health(smk_ctx *c) {
     (void)hipDeviceSynchronize();                        // launches that found the flag set returned at once
     c->seq_fail = e;
     if (e != 3) c->seq_grid = 0;                         // (3: the pipelined step's gate timed out -- nothing wrong with the sequences)
-    if (c->pipe_cnt) (void)hipMemset(c->pipe_cnt, 0, 64);
+    if (c->pipe_cnt) {                                   // the pipelined step's semaphores at rest (see pipe_reset_counters)
+        const unsigned init[16] = {1u, 0u};
+        (void)hipMemcpy(c->pipe_cnt, init, sizeof(init), hipMemcpyHostToDevice);
+    }
     if (c->pipe_sig) { (void)hipMemset(c->pipe_sig, 0, 8); c->pipe_sig_n = 0; }
     *(volatile int *)c->seq_err_host = 0;
     (void)hipMemset(c->seq_err, 0, sizeof(int));
@@ -1622,6 +1629,13 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     Act xs = act(c, "xs", 29, 29, 256 * nbt);
     ConvOpt o; o.relu = 1; o.n_override = 256 * nb;               // conv_search x nb as one N-fused GEMM
     CHK(run_conv(c, "conv_search", se, &xs, B, o, s));
+    if (c->pipe_gate_late) {
+        // pipelined step without the persistent sequence: nothing up to here writes what the previous frame's tail reads (p0 / p1 / p2
+        // exist twice), so the gate sits HERE -- the tail has the whole backbone of this frame to finish beside -- and the heads below
+        // (corr, head0, the decoded position) are the first writers it protects
+        if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, s)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        c->cap_has_seq = true;
+    }
     Act corr = act(c, "corr", 25, 25, 256 * nbt);
     Act h0 = act(c, "head0", 25, 25, 256 * nbt);
     const bool par = parallel_ok(c);
@@ -1774,6 +1788,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         rp.B = B;
         rp.clk = nullptr;
         rp.ring = nullptr; rp.ring_cursor = nullptr; rp.ring_done = nullptr; rp.ring_rows = 0;
+        rp.tail_sem = nullptr;
         if (c->ring_in_step && c->ring_ref) {            // the frame's fp16 logits go to the result ring from post2 itself
             rp.ring = (_Float16 *)c->ring_ref; rp.ring_cursor = c->ring_cursor; rp.ring_done = (unsigned *)(c->ring_cursor + 1);
             rp.ring_rows = c->ring_rows;
@@ -1793,9 +1808,12 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
             cb.n = 1;
             cb.p[0] = c->deferred_mask;
             ProfScope ps(c, s, "refine_chain+mask3", "chain_mask", flop + c->deferred_mask_flop, cbytes + c->deferred_mask_bytes);
+            if (c->pipe_tail_fold) rp.tail_sem = c->pipe_cnt;      // pipelined step: this launch ends the tail, its last workgroup is the "done" mark
             const int rc = launch_chain_mask(rp, cb, s);
+            rp.tail_sem = nullptr;
             if (rc == 0) {
                 c->have_deferred_mask = false;
+                if (c->pipe_tail_fold) c->pipe_done_folded = true;
                 return 0;
             }
             if (rc != 1) return fail(SMK_E_HIP, "chain_mask launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1914,6 +1932,15 @@ static void drop_graph(smk_ctx *c, const GraphKey &key) {
     if (g != c->graphs.end()) { hipGraphExecDestroy(g->second); c->graphs.erase(g); }
     c->graph_has_seq.erase(key);
     c->graph_used.erase(key);
+}
+
+// the pipelined step's semaphores at rest (device idle): one tail "completed" (the first frame has nothing to wait for), no main part
+static int pipe_reset_counters(smk_ctx *c) {
+    if (!c->pipe_cnt) return 0;
+    unsigned init[16] = {1u, 0u};
+    HIPCHK(hipMemcpy(c->pipe_cnt, init, sizeof(init), hipMemcpyHostToDevice));
+    if (c->pipe_sig) { HIPCHK(hipMemset(c->pipe_sig, 0, 8)); c->pipe_sig_n = 0; }
+    return 0;
 }
 
 // order `s` behind the Refine / mask tail a pipelined smk_step left on the side stream (no-op when there is none)
@@ -2352,6 +2379,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "pipe_eager")) g_tune.pipe_eager = value & 3;
     else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
     else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
@@ -2380,7 +2408,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_late", &g_tune.pipe_late}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2443,6 +2471,7 @@ static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, con
         p.ring_box = c->ring_box; p.ring_cursor = c->ring_cursor; p.ring_done = (unsigned *)(c->ring_cursor + 1);
         p.ring_rows = c->ring_rows; p.ring_advance = c->ring_step_refine ? 0 : 1;
     }
+    if (c->pipe_mark_fold) { p.mark = c->pipe_cnt + 2; p.mark_arrived = c->pipe_cnt + 4; }     // pipelined step: the tail's gate waits for this launch
     ProfScope ps(c, s, "decode", "decode", 0.0, (double)B * 30 * 625 * 4);
     if (launch_decode(p, s)) return fail(SMK_E_HIP, "decode launch failed");
     return 0;
@@ -2549,8 +2578,21 @@ static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *ref
 // either written behind the gate or exists twice (p0, p1).  The join is an in-stream gate kernel (misc_kernels.hip pipe_gate_kernel),
 // not an event: a cross-queue event wait on the critical path costs 15-22 us here (smk_tune "pipe_join" = 0 keeps that form --
 // three graphs, front | event wait | mid -- for the A/B).
+static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
+                                  float *mask, double *box_out, float *refine_out, hipStream_t s);
 static int step_pipelined(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
                           float *mask, double *box_out, float *refine_out, hipStream_t s) {
+    const int rc = step_pipelined_enqueue(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, s);
+    if (rc) {
+        // a main part without its tail (or the reverse) would leave the semaphores unbalanced: drain and start over
+        (void)hipDeviceSynchronize();
+        (void)pipe_reset_counters(c);
+        c->tail_pending = false;
+    }
+    return rc;
+}
+static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, const double *target_wh, float *cls, float *loc,
+                                  float *mask, double *box_out, float *refine_out, hipStream_t s) {
     const int par = c->pipe_parity;
     c->parity_now = par;
     int64_t pk, wi;
@@ -2559,23 +2601,36 @@ static int step_pipelined(smk_ctx *c, const float *x, int B, int flags, const do
     const bool gate = g_tune.pipe_join != 0;
     const bool sig = gate && g_tune.pipe_sig == 1 && c->pipe_sig;
     const bool tgate = gate && g_tune.pipe_sig == 2;      // the tail's start is a gate kernel too (A/B)
-    const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0);
+    // where the main gate sits: in front of layer2 when that is the persistent sequence (it must own every CU), else in front of the
+    // heads -- the first launches that write what the tail reads (smk_tune pipe_late = 0 keeps it in front of layer2 for the A/B)
+    const bool late = gate && g_tune.pipe_late && !(seq_wanted(c, B) && !parallel_ok(c));
+    const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0) | (late ? 1 << 20 : 0);
     const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io};
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
     auto main_ = [&](hipStream_t st) {
         CHK(front(st));
-        if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
-        c->cap_has_seq = true;              // (the gate reports through the sequence failure flag: checked like a sequence launch)
-        CHK(mid(st));
+        if (!late) {
+            if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+            c->cap_has_seq = true;          // (the gate reports through the sequence failure flag: checked like a sequence launch)
+        }
+        c->pipe_gate_late = late;           // ... else seq_track places it in front of the heads
+        c->pipe_mark_fold = tgate;          // the decode launch's last writer is the main part's completion mark
+        const int rcm = mid(st);
+        c->pipe_mark_fold = false;
+        c->pipe_gate_late = false;
+        CHK(rcm);
         if (sig && launch_pipe_mark(c->pipe_sig, st)) return fail(SMK_E_HIP, "pipe_mark launch failed");
-        if (tgate && launch_pipe_mark(c->pipe_cnt + 2, st)) return fail(SMK_E_HIP, "pipe_mark launch failed");
         return 0;
     };
     auto tail = [&](hipStream_t st) {
         if (tgate && launch_pipe_tail_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_tail_gate launch failed");
-        CHK(step_tail(c, B, mask, box_out, refine_out, st));
-        if (gate && launch_pipe_done(c->pipe_cnt, st)) return fail(SMK_E_HIP, "pipe_done launch failed");
+        c->pipe_tail_fold = gate;           // a tail that ends in chain_mask_kernel lets its last workgroup be the "done" mark
+        c->pipe_done_folded = false;
+        const int rct = step_tail(c, B, mask, box_out, refine_out, st);
+        c->pipe_tail_fold = false;
+        CHK(rct);
+        if (gate && !c->pipe_done_folded && launch_pipe_done(c->pipe_cnt, st)) return fail(SMK_E_HIP, "pipe_done launch failed");
         return 0;
     };
     const bool graphs = c->graph_mode;
@@ -2675,17 +2730,16 @@ int smk_set_pipeline(smk_ctx *c, int depth) {
         if (!c->buf.count("p0#1")) {
             CHK(alloc_buf(c, "p0#1", c->buf_elems.at("p0")));
             CHK(alloc_buf(c, "p1#1", c->buf_elems.at("p1")));
+            CHK(alloc_buf(c, "p2#1", c->buf_elems.at("p2")));
         }
         if (!c->pipe_stream) HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
         if (!c->pipe_cnt) HIPCHK(hipMalloc((void **)&c->pipe_cnt, 64));
-        HIPCHK(hipMemset(c->pipe_cnt, 0, 64));                  // tails completed = gates passed = 0
         if (!c->pipe_sig) {
             int can = 0;
             (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
             if (can && hipExtMallocWithFlags((void **)&c->pipe_sig, 8, hipMallocSignalMemory) != hipSuccess) { c->pipe_sig = nullptr; (void)hipGetLastError(); }
         }
-        if (c->pipe_sig) HIPCHK(hipMemset(c->pipe_sig, 0, 8));
-        c->pipe_sig_n = 0;
+        CHK(pipe_reset_counters(c));
         if (c->pipe_ev.empty()) {
             c->pipe_ev.resize(16);
             for (auto &e : c->pipe_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

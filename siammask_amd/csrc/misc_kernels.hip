@@ -543,7 +543,12 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
         if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; ba = q; }
     }
     const int rm = bi - (bi / SS) * SS, y = rm / p.S, x = rm - y * p.S;
-    if (p.pos_out) { p.pos_out[2 * b] = y; p.pos_out[2 * b + 1] = x; }
+    if (p.pos_out) {
+        // (device-coherent stores: with p.mark set, the Refine tail of a pipelined step reads the position from the side stream as soon
+        //  as the mark below is visible -- before this kernel's end has written the XCD's L2 back)
+        __hip_atomic_store(p.pos_out + 2 * b, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.pos_out + 2 * b + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (p.box_out) {
         const unsigned long long *pb = (const unsigned long long *)(p.part_box + ((size_t)b * 8 + ba) * 8);
         double *o = p.box_out + 8 * b;
@@ -567,6 +572,17 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
         }
     }
     __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p.mark) {
+        // pipelined step: the LAST stream's writer tells the side stream's gate that every position of this frame is in memory
+        // (semaphore V; pipe_tail_gate_kernel is the P) -- instead of a one-thread kernel behind this one, 4 us in front of the next
+        // frame's first launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(p.mark_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (unsigned)p.B - 1) {
+            __hip_atomic_store(p.mark_arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.mark, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 
@@ -624,57 +640,50 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
     }
 }
 
-// ---- pipelined frame steps (smk_set_pipeline): the in-stream join with the side stream's Refine / mask tail -----------------
-// A cross-queue event wait costs 15-22 us on this platform (measured: profiles/r05a_pipelined_timeline.txt), more than half of what
-// the overlap saves.  The join is therefore a one-wave GATE kernel in the step's own stream: it polls a device counter that a
-// one-thread kernel at the end of the tail advances.  cnt[0] = tails completed, cnt[1] = gates passed: gate number g (0, 1, ...) lets
-// its stream continue once g tails have completed, i.e. it waits for the tail of the previous frame; baked launch arguments, so it
-// replays from a captured graph.  While it polls, every CU but the gate's wave slot is free for the tail (the front end in front of
-// the gate has drained: same stream), and the tail never waits for anything behind the gate -- no deadlock.  A tail that does not
-// arrive within 0.2 s raises the sequence failure flag (code 3): the caller re-submits, as for a barrier time-out.
-__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *cnt, int *err, int *err_host) {
-    if (threadIdx.x != 0) return;
-    const unsigned want = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- pipelined frame steps (smk_set_pipeline): the joins between the step's stream and the side stream's Refine / mask tail ----------
+// A cross-queue event wait costs 10-22 us on this platform and an event record between two kernels of one stream 4-8 us
+// (profiles/r05a_pipelined_timeline_event_join.txt, r05c_order_probe.txt) -- more than half of what the overlap saves.  Both joins are
+// therefore one-wave GATE kernels that poll device counters, replayable from captured graphs (baked arguments).  While the main gate
+// polls, everything in front of it in its stream has drained and the tail never waits for anything behind it; while the tail's gate
+// polls, it holds one wave slot beside the next frame's kernels -- no deadlock.  A partner that does not arrive within 0.2 s raises the
+// sequence failure flag (code 3): the caller re-submits, as for a barrier time-out.
+// Both joins are SEMAPHORES with one consumer each: P = poll until the count is positive, then take one; V = add one.
+//   sem_tail (cnt[0], starts at 1): V by the tail's end (pipe_done_kernel, or chain_mask_kernel's last workgroup), P by the gate in
+//       front of the next frame's persistent launch;
+//   sem_main (cnt[2], starts at 0): V by the decode launch's last writer (or pipe_mark_kernel), P by the gate at the head of the tail.
+__device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    while (__hip_atomic_load(sem, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(8);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {          // 100 MHz: 0.2 s
             __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
+            return;                                                          // (the count is left alone: the host resets it)
         }
     }
-    __hip_atomic_store(cnt + 1, want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_sub(sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *cnt, int *err, int *err_host) {
+    if (threadIdx.x == 0) pipe_sem_p(cnt, err, err_host);
 }
 __global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *cnt) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the main part's completion mark for the side stream: the tail's start is a hipStreamWaitValue32 on this counter (signal memory;
-// 3-4 us from the write to the waiter's first instruction, tools/order_probe.hip) instead of an event record in the step's own
-// stream (4-8 us in front of the next frame's first kernel) plus a cross-queue event wait (10-12 us)
-__global__ __launch_bounds__(64) void pipe_mark_kernel(unsigned *sig) {
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// smk_tune pipe_sig = 2: the tail's START is a gate as well -- one wave at the head of the tail graph polls the counter MARK advances
-// (cnt[2] = main parts completed, cnt[3] = tail gates passed).  It becomes resident as soon as the previous tail has drained, i.e. it
-// polls THROUGH the next frame's persistent launch and must fit beside a conv_seq_kernel workgroup (one wave, < 16 VGPRs, no LDS).
+// the tail's START as a gate as well (smk_tune pipe_sig = 2, the default): one wave at the head of the tail graph.  It becomes resident as
+// soon as the previous tail has drained, i.e. it polls THROUGH the next frame's persistent launch and must fit beside a
+// conv_seq_kernel workgroup: one wave, 8 VGPRs, no LDS against that kernel's 2 x 248 of a SIMD's 512 VGPRs -- if it ever did not, the
+// persistent launch would not get its CU, decode would never run, and both gates' 0.2 s limits raise the failure flag (loud, no hang).
 __global__ __launch_bounds__(64) void pipe_tail_gate_kernel(unsigned *cnt, int *err, int *err_host) {
-    if (threadIdx.x != 0) return;
-    const unsigned want = __hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(cnt + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-        __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {
-            __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
-    __hip_atomic_store(cnt + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) pipe_sem_p(cnt + 2, err, err_host);
 }
 int launch_pipe_tail_gate(unsigned *cnt, int *err, int *err_host, void *stream) {
     hipLaunchKernelGGL(pipe_tail_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt, err, err_host);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// (smk_tune pipe_sig = 1: the main part's completion mark in SIGNAL memory for a hipStreamWaitValue32 on the side stream -- 3-4 us in
+//  the two-kernel probe, +50 % per step in the real loop: kept as the measured alternative, profiles/r05e_pipe_sig_ab.txt)
+__global__ __launch_bounds__(64) void pipe_mark_kernel(unsigned *sig) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 int launch_pipe_mark(unsigned *sig, void *stream) {
     hipLaunchKernelGGL(pipe_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sig);

@@ -216,10 +216,13 @@ struct Tuning {
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
-    int pipe_sig = 0;          // pipelined frame step, A/B knob: 1 = the tail's start waits for a counter in signal memory (hipStreamWaitValue32) that a
-                               // one-thread kernel behind decode advances -- 3-4 us in the two-kernel probe (tools/order_probe.hip) but 0.85 ms per step
-                               // against 0.557 in the real loop (profiles/r05e_pipe_sig_ab.txt: a queue parked on a wait-value stalls the other queue's
-                               // dispatches); 0 (default) = hipEventRecord in the step's stream + hipStreamWaitEvent
+    int pipe_late = 1;         // pipelined frame step outside the persistent sequence's batches: the main gate in front of the heads instead of in front of
+                               // layer2 (the tail overlaps the whole backbone of the next frame; p2 exists twice as well)
+    int pipe_sig = 2;          // pipelined frame step, how the side stream learns that decode(f) is done: 2 (default) = a one-wave gate kernel at the head of
+                               // the tail polls a semaphore the decode launch's last writer raises (it polls through the next frame's persistent launch,
+                               // beside it: 0.531-0.541 ms per step against 0.556 for 0 and 0.563-0.565 serial, profiles/r05f_pipe_sig_ab.txt);
+                               // 0 = hipEventRecord in the step's stream + hipStreamWaitEvent; 1 = hipStreamWaitValue32 on signal memory (3-4 us in the
+                               // two-kernel probe, 0.85 ms per step in the real loop, profiles/r05e_pipe_sig_ab.txt)
     int pipe_eager = 0;        // pipelined frame step, A/B knob: bit 0 = the front end (stem + layer1) as eager launches instead of a graph,
                                // bit 1 = the Refine / mask tail as eager launches
 };
@@ -329,6 +332,8 @@ struct DecodeParams {
     int *ring_cursor;
     unsigned *ring_done;
     int ring_rows, ring_advance;
+    // pipelined frame step: the last stream's writer adds one to *mark (the semaphore the tail's gate waits on); mark_arrived counts streams
+    unsigned *mark, *mark_arrived;
 };
 
 // result ring (misc_kernels.hip ring_commit_kernel): row (cursor % rows) <- this frame's box + fp16 Refine logits; cursor advances
@@ -405,6 +410,9 @@ struct RefineChainParams {
     int *ring_cursor;
     unsigned *ring_done;
     int ring_rows;
+    // pipelined frame step, chain_mask_kernel only: the context's counter block (engine pipe_cnt); the launch's last workgroup adds one
+    // to [0] (the tail semaphore), [5] counts the workgroups' arrivals; nullptr = not the end of a pipelined tail
+    unsigned *tail_sem;
 };
 int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch

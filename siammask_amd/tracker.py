@@ -40,8 +40,12 @@ def _mean_colour(frame):
 
 
 class DeviceTracker(object):
-    def __init__(self, model, hp=None):
+    def __init__(self, model, hp=None, pipeline=False):
+        """pipeline=True: the frame steps are software-pipelined (Custom.set_pipeline): the host reads the decoded box and updates
+        the tracker state (:240-250,302-305) while the Refine mask of the same frame is still being computed on a side stream; the
+        mask is joined only where it is pasted back (:257-284) -- same results."""
         self.model = model
+        self.pipeline = bool(pipeline)
         self.p = TrackerConfig(hp)
         self.refine = model.variant == "sharp"
         # config_davis.json hp sets out_size 127 for the Refine output; the base head is 63x63
@@ -65,6 +69,8 @@ class DeviceTracker(object):
             s_z.append(round(np.sqrt(wc_z * hc_z)))
         z = preproc.crop_batch(frame, pos, p.exemplar_size, s_z, avg)
         self.model.template(z)
+        if self.pipeline and self.refine:
+            self.model.set_pipeline(True)
         H, W = int(frame.shape[-3]), int(frame.shape[-2])
         self.state = {"im_h": H, "im_w": W, "avg_chans": avg, "target_pos": pos.copy(), "target_sz": sz.copy(),
                       "score": np.zeros(B), "mask": None}
@@ -106,6 +112,7 @@ class DeviceTracker(object):
             bbs = [preproc_back_box(crop_box[b], (int(delta_y[b]), int(delta_x[b])), (st["im_w"], st["im_h"]), p,
                                     self.mask_size) for b in range(B)]
             if self.refine:
+                self.model.pipeline_join()                            # (a no-op for serial steps)
                 logits = out["refine"]
             else:                                                     # base: one column of the 63x63 head (:259-260)
                 m = out["mask"]

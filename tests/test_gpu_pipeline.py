@@ -87,15 +87,18 @@ def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
     assert torch.equal(r0, r1)
 
 
-def test_event_join_form_is_the_same_arithmetic():
-    """smk_tune pipe_join = 0: the first form of the pipeline (three graphs, cross-queue event wait instead of the in-stream gate
-    kernel) -- kept for the A/B; same rows"""
-    old = _lib.tune_get("pipe_join")
+@pytest.mark.parametrize("knobs", [dict(pipe_join=0), dict(pipe_sig=0), dict(pipe_sig=1), dict(pipe_eager=2)])
+def test_other_join_forms_are_the_same_arithmetic(knobs):
+    """the measured alternatives of the two joins, kept for the A/B (profiles/r05a_*, r05e_*, r05f_*): pipe_join = 0 -- three graphs and
+    a cross-queue event wait instead of the in-stream gate kernel; pipe_sig = 0 -- the tail's start by event record + wait instead
+    of the gate that polls beside the persistent launch; pipe_sig = 1 -- hipStreamWaitValue32 on signal memory; pipe_eager = 2 -- the
+    tail as eager launches.  Same rows."""
+    old = {k: _lib.tune_get(k) for k in knobs}
     try:
-        _lib.tune(pipe_join=0)
+        _lib.tune(**knobs)
         test_pipelined_rows_equal_serial_rows(8, "f16", 5)
     finally:
-        _lib.tune(pipe_join=old)
+        _lib.tune(**old)
 
 
 def test_pipelined_200_steps_clean_and_deterministic():
