@@ -83,13 +83,13 @@ class Workload(object):
         # software-pipelined steps (smk_set_pipeline): the Refine / mask tail of frame f beside stem + layer1 of frame f + 1 -- the
         # next crop depends on the decoded box only (tools/test.py:240-250,302-308).  Every frame's tail is inside the timed
         # region: the loop ends with a device-wide synchronisation.
-        self.pipeline = bool(pipeline and fused and self.refine)
+        self.pipeline = int(pipeline) if (pipeline and fused and self.refine) else 0      # 0 serial, 1 / 2 = smk_set_pipeline depth
         if self.pipeline:
-            self.model.set_pipeline(True)
+            self.model.set_pipeline(self.pipeline)
 
-    def set_pipeline(self, on):
+    def set_pipeline(self, depth):
         self.sync()
-        self.pipeline = bool(on and self.fused and self.refine)
+        self.pipeline = int(depth) if (depth and self.fused and self.refine) else 0
         self.model.set_pipeline(self.pipeline)
 
     def join(self):
@@ -260,16 +260,24 @@ def frame_latency(w, n=40):
         ev[i][0].record(s)
         w.step(i)
         ev[i][1].record(s)
-        if w.pipeline:
+        if w.pipeline >= 2:
+            # depth 2: this step launched the second part of the PREVIOUS frame's tail; observe it without launching this frame's
+            if i:
+                w.model.pipeline_join(s2, launch_pending=False)
+                ev[i - 1][2].record(s2)
+        elif w.pipeline:
             w.model.pipeline_join(s2)
             ev[i][2].record(s2)
         else:
             ev[i][2].record(s)
+    if w.pipeline >= 2:
+        w.model.pipeline_join(s2)
+        ev[n - 1][2].record(s2)
     w.sync()
     box = sorted(e[0].elapsed_time(e[1]) for e in ev[5:])
     mask = sorted(e[0].elapsed_time(e[2]) for e in ev[5:])
     return {"box_ms_median": round(box[len(box) // 2], 4), "mask_ms_median": round(mask[len(mask) // 2], 4),
-            "mask_ms_max": round(mask[-1], 4), "pipelined": w.pipeline, "frames": len(box)}
+            "mask_ms_max": round(mask[-1], 4), "pipeline_depth": w.pipeline, "frames": len(box)}
 
 
 CONV_FAMILY = "conv_igemm+conv3x3_halo+conv_wreg"       # one convolution (or a merged batch) per launch
@@ -685,6 +693,9 @@ def main():
                     help="untimed clock/cache warm-up before the W warm-up steps")
     ap.add_argument("--serial", action="store_true",
                     help="serial frame steps (the round 1-4 form) instead of the software-pipelined ones (smk_set_pipeline)")
+    ap.add_argument("--pipeline-depth", type=int, default=1, choices=(1, 2),
+                    help="smk_set_pipeline depth: 1 = the Refine / mask tail of frame f beside the front end of frame f + 1; 2 = its second part "
+                         "(Refine chain + mask head) beside the HEADS of frame f + 1 (batches that run the persistent sequence; else like 1)")
     ap.add_argument("--unfused", action="store_true",
                     help="time the reference call sequence (track_mask, track_refine(fixed pos)) instead of the "
                          "fused device-resident step")
@@ -733,7 +744,7 @@ def main():
         w = StubWorkload(rank, batch=args.batch or 8)
     else:
         w = Workload(args.workload, dev, rank, n_inputs=args.inputs, batch=args.batch, fused=not args.unfused,
-                     pipeline=not args.serial)
+                     pipeline=0 if args.serial else args.pipeline_depth)
         w.no_ring = args.no_ring
     res = Results(w, args.steps)
     prewarm(w, res, 0.0 if args.stub else args.prewarm_seconds)
@@ -756,11 +767,16 @@ def main():
             latency = frame_latency(w)
             if w.pipeline and not args.no_long:
                 # the same loop with serial steps (round 1-4 form) beside the pipelined `value`: what the overlap is worth on this box
-                w.set_pipeline(False)
+                depth = w.pipeline
+                w.set_pipeline(0)
                 ds = timed_run(w, args.steps, 5, 1, gather, res)
                 serial_cmp = {"fps": round(w.B * args.steps / ds, 2), "ms_per_step": round(ds / args.steps * 1e3, 4),
                               "latency": frame_latency(w)}
-                w.set_pipeline(True)
+                if depth >= 2:              # ... and depth 1 beside depth 2
+                    w.set_pipeline(1)
+                    d1 = timed_run(w, args.steps, 5, 1, gather, res)
+                    serial_cmp["depth1"] = {"fps": round(w.B * args.steps / d1, 2), "ms_per_step": round(d1 / args.steps * 1e3, 4)}
+                w.set_pipeline(depth)
         except Exception as e:  # noqa: BLE001
             latency = {"error": str(e)[:200]}
 
@@ -847,9 +863,11 @@ def main():
                        "persistent_sequences": seq,
                        "results_kept_by": ("library result ring: one launch at the end of the step's graph (smk_set_result_ring)"
                                            if getattr(res, "ring", False) else "two torch copies per step"),
-                       "step": (("pipelined (smk_set_pipeline): [stem+layer1] | [layer2 .. heads -> device decode] on the step's stream, "
-                                 "[track_refine + mask head] of the same frame on a side stream beside the next frame's front end; "
-                                 "three graphs, two events per frame") if getattr(w, "pipeline", False) else
+                       "step": (("pipelined, depth %d (smk_set_pipeline): [stem+layer1 | gate | layer2 .. heads -> device decode] on the step's stream; "
+                                 "[track_refine + mask head] of the same frame on a side stream beside the next frame's front end"
+                                 "%s; joins are one-wave gate kernels on device semaphores, every frame's tail inside the timed region"
+                                 % (w.pipeline, " (depth 2: the Refine chain + mask head beside the next frame's HEADS)" if w.pipeline >= 2 else ""))
+                                if getattr(w, "pipeline", 0) else
                                 "track_mask -> device decode -> track_refine, one graph" if w.fused
                                 else "track_mask ; track_refine(fixed pos)"),
                        "gflop_per_frame": w.gflop_per_frame()},

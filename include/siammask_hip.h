@@ -161,9 +161,16 @@ int smk_result_ring_cursor(smk_ctx *ctx, int *frames_out, int reset, void *strea
  * refine_out (and the ring's logits row + cursor) of frame f are complete once the NEXT smk_step's decode is, or behind
  * smk_pipeline_join(ctx, any_stream), which orders that stream behind the outstanding tail (every other entry point of the
  * context joins implicitly).  Results are bit-identical to the serial step.  Costs a second copy of p0 / p1 (4 MB per stream of the
- * batch in fp16).  depth 0 = serial (default).  Synchronises the device. */
+ * batch in fp16).  depth 0 = serial (default).  Synchronises the device.
+ * depth 2 (throughput mode; fp16 contexts, batches that run the persistent sequence; otherwise it behaves like depth 1): the tail is
+ * cut in two -- the window convolutions + deconv + v*.2 run beside the next frame's front end as in depth 1, the Refine chain + mask
+ * head (one low-occupancy launch) wait until the NEXT frame's persistent launch has left and run beside that frame's heads.  That
+ * second part is launched by the next smk_step; smk_pipeline_join (and every other entry point) launches it at once.  mask_out /
+ * refine_out of frame f are then complete behind smk_pipeline_join only (or one smk_step later: smk_pipeline_observe orders a stream
+ * behind what has been launched so far WITHOUT launching a pending second part).  Same bits.  One more copy of head0. */
 int smk_set_pipeline(smk_ctx *ctx, int depth);
 int smk_pipeline_join(smk_ctx *ctx, void *stream);
+int smk_pipeline_observe(smk_ctx *ctx, void *stream);
 
 /* persistent per-XCD convolution sequences (fp16, batch 8: ResNet layer2 / layer3 / adjust run as ONE conv_seq_kernel launch,
  * one workgroup per CU, image b on XCD b % 8).  The kernel needs every workgroup resident at once; when that fails (a

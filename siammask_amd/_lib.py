@@ -25,7 +25,7 @@ TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 # every symbol include/siammask_hip.h declares
 SYMBOLS = (
     "smk_version", "smk_last_error", "smk_create", "smk_destroy", "smk_set_weight",
-    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status", "smk_seq_sync_check", "smk_set_result_ring", "smk_result_ring_cursor", "smk_set_pipeline", "smk_pipeline_join",
+    "smk_finalize_weights", "smk_template", "smk_track", "smk_refine", "smk_set_decode_params", "smk_decode", "smk_step", "smk_set_graph_mode", "smk_seq_status", "smk_seq_sync_check", "smk_set_result_ring", "smk_result_ring_cursor", "smk_set_pipeline", "smk_pipeline_join", "smk_pipeline_observe",
     "smk_debug_read", "smk_debug_seq_inject", "smk_tune", "smk_tune_get", "smk_profile", "smk_profile_dump", "smk_op_conv2d_ex", "smk_op_conv2d", "smk_op_dw_xcorr",
     "smk_op_maxpool3x3s2", "smk_op_conv_seq", "smk_host_conv2d_ex", "smk_host_plan_conv", "smk_bench_conv", "smk_packed_size", "smk_export_packed",
     "smk_import_packed", "smk_crop_resize", "smk_paste_mask", "smk_paste_labels",
@@ -96,6 +96,7 @@ def lib():
     L.smk_set_result_ring.argtypes = [vp, vp, vp, ci, ci]
     L.smk_set_pipeline.argtypes = [vp, ci]
     L.smk_pipeline_join.argtypes = [vp, vp]
+    L.smk_pipeline_observe.argtypes = [vp, vp]
     L.smk_result_ring_cursor.argtypes = [vp, ctypes.POINTER(ci), ci, vp]
     L.smk_seq_sync_check.argtypes = [vp, vp, ctypes.POINTER(ci)]
     L.smk_tune.argtypes = [ctypes.c_char_p, ci]

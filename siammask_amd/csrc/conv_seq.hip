@@ -284,6 +284,15 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
             __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int i = 8; i < 32; ++i) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // the pairs' exchange counters
+            if (a.exit_sem) {
+                // pipelined frame step, depth 2: the chip is free for the previous frame's Refine chain + mask head from here on -- the
+                // last of the eight teams to leave raises the semaphore its gate polls (instead of a one-thread kernel behind this one)
+                const unsigned t = __hip_atomic_fetch_add(a.exit_sem + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == 7u) {
+                    __hip_atomic_store(a.exit_sem + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(a.exit_sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 }

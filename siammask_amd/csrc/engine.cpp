@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>
@@ -274,7 +275,8 @@ struct smk_ctx {
     double *ring_box = nullptr;
     void *ring_ref = nullptr;
     int ring_rows = 0;
-    int *ring_cursor = nullptr;      // device [2]: [0] frames committed, [1] arrival counter of the launch that advances it
+    int *ring_cursor = nullptr;      // device [4]: [0] frames committed, [1] arrival counter of the launch that advances it; [2] / [3] the same for the box
+                                     // rows alone while frame steps are pipelined two deep (decode then runs ahead of the previous frame's chain)
     bool ring_in_step = false;       // smk_step is recording: decode / the Refine chain take the ring writes with them
     bool ring_step_refine = false;   // ... and a Refine launch follows the decode launch
     bool ring_ref_folded = false;    // the chain launch took the fp16 logits + the cursor
@@ -316,6 +318,10 @@ struct smk_ctx {
     bool pipe_tail_has_mask = false; // (A/B knob pipe_eager bit 1) mid's capture handed the mask head to the tail
     unsigned *pipe_cnt = nullptr;    // device [16] u32: [0] semaphore "tails completed" (starts at 1), [2] semaphore "main parts completed",
                                      // [4] / [5] arrival counters of decode's streams / chain_mask's workgroups (misc_kernels.hip pipe_*)
+    bool pipe_two = false;           // (recording a depth-2 pipelined step) decode keeps its own ring cursor
+    bool pipe_seq_exit = false, pipe_seq_exit_done = false;   // ... and the sequence launch raises the "chip is free" semaphore when it leaves
+    bool tail2_pending = false;      // depth 2: the second part of the last frame's tail (chain + mask head) has not been launched yet
+    GraphKey tail2_key, tail2_gated_key;   // ... its graph without / with the gate (flush form / the form the next step launches)
     bool pipe_gate_late = false;     // (recording a pipelined step) seq_track launches the main gate in front of the heads
     bool pipe_mark_fold = false, pipe_tail_fold = false, pipe_done_folded = false;   // (while a pipelined step's parts are being recorded)
     unsigned *pipe_sig = nullptr;    // signal memory: main parts completed (pipe_mark_kernel); the tail's hipStreamWaitValue32 target
@@ -632,6 +638,7 @@ static Act act(smk_ctx *c, const char *name, int H, int W, int C) {
     // p0 / p1 exist twice while frame steps are pipelined (the tail of frame f reads one copy, the front of f + 1 writes the other)
     if (c->parity_now && name[0] == 'p' && (name[1] == '0' || name[1] == '1' || name[1] == '2') && !name[2])
         a.p = c->buf.at(name[1] == '0' ? "p0#1" : (name[1] == '1' ? "p1#1" : "p2#1"));
+    else if (c->parity_now && c->pipe_depth >= 2 && !strcmp(name, "head0")) a.p = c->buf.at("head0#1");   // (depth 2: the mask head of frame f runs beside corr_head of f + 1)
     else
     a.p = c->buf.at(name);
     a.H = H; a.W = W; a.C = C;
@@ -1078,6 +1085,9 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         a.xch = c->seq_xch;
         a.err = c->seq_err;
         a.err_host = c->seq_err_hdev;
+        // pipelined step, depth 2: the last launch of the list tells the previous frame's chain / mask-head launch that the chip is free
+        a.exit_sem = (c->pipe_seq_exit && i0 + SEQ_MAX >= n) ? c->pipe_cnt + 7 : nullptr;
+        if (a.exit_sem) c->pipe_seq_exit_done = true;
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
         seq_fuse_pairs(a.L, a.n, B, nullptr, c->seq_xch != nullptr && (c->seq_grid >> 3) % 2 == 0 && (c->seq_grid >> 4) <= SEQ_XCH_PAIRS);   // (a pair never straddles two launches)
         seq_fuse_triples(a.L, a.n, B, c->seq_wstd.data() + i0);
@@ -1163,6 +1173,7 @@ static int seq_health(smk_ctx *c) {
     c->graph_has_seq.clear();
     c->seq_pending = false;
     c->tail_pending = false;                             // (the device has drained)
+    c->tail2_pending = false;                            // (a pending second tail part belongs to an invalid frame: dropped with its graph)
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
     if (e == 3)
@@ -1710,7 +1721,12 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
 }
 
 // Refine.forward(test=True), custom.py:131-154, with a per-item position
-static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
+// part: 0 = all of it; 1 = the window convolutions + deconv + v*.2 (what reads the kept features and the position); 2 = the chain launch
+// (what reads only part 1's outputs and, for the mask head, head0).  The split exists for the fp16 chain path only (depth-2 pipelining).
+static bool refine_splittable(const smk_ctx *c, int B) {
+    return c->dtype == DT_F16 && g_tune.chain && !parallel_ok(c) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
+}
+static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0) {
     const int *pos = c->pos_dev;
     Act corr = act(c, "corr", 25, 25, 256 * 3);
     Act p0 = act(c, "p0", 125, 125, 64), p1 = act(c, "p1", 63, 63, 256), p2 = act(c, "p2", 31, 31, 512);
@@ -1741,21 +1757,21 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
     ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
     Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
     const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
-    if (merged) {
+    if (merged && part != 2) {
         // the window convs only depend on the kept backbone features and pos: one launch with deconv
         w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
         // smk_tune "rf_wreg": bit 0 the four members on the register-fed kernel, bits 4..6 its tile code (0 = 3: 64x64; 6 = 128x64)
         if (g_tune.rf_wreg & 1) w2.wreg = w1.wreg = w0.wreg = od.wreg = ((g_tune.rf_wreg >> 4) & 7) ? ((g_tune.rf_wreg >> 4) & 7) : 3;
         CHK(run_conv_jobs(c, {{"v2.0", &p2, &v2a, w2}, {"v1.0", &p1, &v1a, w1}, {"v0.0", &p0, &v0a, w0},
                               {"deconv", &corr, &d1, od}}, B, 0, s));
-    } else {
+    } else if (part != 2) {
         CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
     }
     Act d = act(c, "rf_d", 15, 15, 32);
     if (c->dtype == DT_F16 && g_tune.chain && !par) {
         // fp16: v*.2 in one merged launch (they only depend on v*.0), then the nine sequential convolutions
         // h2 -> post0 -> h1 -> post1 -> h0 -> post2 as ONE launch with the activations in LDS (refine_chain.hip)
-        if (!merged) {
+        if (!merged && part != 2) {
             CHK(run_conv(c, "v2.0", p2, &v2a, B, w2, s));
             CHK(run_conv(c, "v1.0", p1, &v1a, B, w1, s));
             CHK(run_conv(c, "v0.0", p0, &v0a, B, w0, s));
@@ -1765,7 +1781,8 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s) {
         r3l.tile_code = g_tune.rf_tile2;          // (A/B knob: workgroup tile of the merged v*.2 launch; 0 = the lead's own choice, 64x64)
         ConvOpt r3w = r3;
         if ((g_tune.rf_wreg & 2) && merged) r3l.wreg = r3w.wreg = ((g_tune.rf_wreg >> 8) & 7) ? ((g_tune.rf_wreg >> 8) & 7) : 3;      // bit 1: the v*.2 launch, bits 8..10 its tile code
-        CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3w}, {"v0.2", &v0a, &V0, r3w}}, B, 0, s));
+        if (part != 2) CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3w}, {"v0.2", &v0a, &V0, r3w}}, B, 0, s));
+        if (part == 1) return 0;
         static const char *ids[9] = {"h2.0", "h2.2", "post0", "h1.0", "h1.2", "post1", "h0.0", "h0.2", "post2"};
         static const int geo[9][3] = {{225, 32, 32}, {225, 32, 32}, {961, 32, 16}, {961, 16, 16}, {961, 16, 16},
                                       {3721, 16, 4}, {3721, 4, 4}, {3721, 4, 4}, {16129, 4, 1}};   // pixels, Cin, Cout
@@ -1943,8 +1960,31 @@ static int pipe_reset_counters(smk_ctx *c) {
     return 0;
 }
 
+static int launch_graph(smk_ctx *c, const GraphKey &key, hipStream_t s);
+// depth-2 pipelining: the second part of the last frame's tail waits for a next frame that may never come -- whoever needs the
+// results (or is about to drop the graphs) launches it without its gate
+static int pipe_flush(smk_ctx *c) {
+    if (!c->tail2_pending) return 0;
+    c->tail2_pending = false;
+    CHK(launch_graph(c, c->tail2_key, c->pipe_stream));
+    hipEvent_t e = c->pipe_ev[c->pipe_ev_next++ % c->pipe_ev.size()];
+    HIPCHK(hipEventRecord(e, c->pipe_stream));
+    c->tail_ev = e;
+    c->tail_pending = true;
+    return 0;
+}
+
+// before the captured graphs are dropped: nothing of a pipelined step may still be waiting to be launched or running
+static int pipe_quiesce(smk_ctx *c) {
+    CHK(pipe_flush(c));
+    if (c->pipe_stream) HIPCHK(hipStreamSynchronize(c->pipe_stream));
+    c->tail_pending = false;
+    return 0;
+}
+
 // order `s` behind the Refine / mask tail a pipelined smk_step left on the side stream (no-op when there is none)
 static int pipe_join(smk_ctx *c, hipStream_t s, bool clear) {
+    CHK(pipe_flush(c));
     if (!c->tail_pending) return 0;
     HIPCHK(hipStreamWaitEvent(s, c->tail_ev, 0));
     if (clear) c->tail_pending = false;
@@ -2075,6 +2115,7 @@ int smk_set_weight(smk_ctx *c, const char *name, const float *data, const int64_
 int smk_finalize_weights(smk_ctx *c) {
     if (!c) return fail(SMK_E_ARG, "smk_finalize_weights: ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_quiesce(c));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
@@ -2157,6 +2198,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
                     h.abi, h.dtype, h.variant, smk_version(), c->dtype, c->variant);
     if (h.total_bytes != bytes || h.n_conv < 1 || h.n_conv > 256) return fail(SMK_E_WEIGHT, "smk_import_packed: size mismatch");
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_quiesce(c));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
@@ -2380,6 +2422,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
     else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
+    else if (!strcmp(key, "pipe_two_form")) g_tune.pipe_two_form = value != 0;
     else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
@@ -2408,7 +2451,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_late", &g_tune.pipe_late}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2469,7 +2512,15 @@ static int seq_decode(smk_ctx *c, const float *cls, const float *loc, int B, con
     fill_decode_params(c, cls, loc, B, target_wh, pos_out, box_out, p);
     if (c->ring_in_step && c->ring_box && box_out) {     // result ring: the box goes to the ring from the decode launch itself
         p.ring_box = c->ring_box; p.ring_cursor = c->ring_cursor; p.ring_done = (unsigned *)(c->ring_cursor + 1);
-        p.ring_rows = c->ring_rows; p.ring_advance = c->ring_step_refine ? 0 : 1;
+        p.ring_rows = c->ring_rows; p.ring_advance = 1;
+        if (c->ring_step_refine) {
+            // A Refine launch follows and commits the frame (cursor [0]).  With frame steps pipelined two deep this launch runs BEFORE the
+            // previous frame's chain has done so, so the box rows follow their own cursor ([2], arrivals [3]) in every mode; both cursors
+            // advance once per frame whatever mix of step forms a caller uses.
+            p.ring_cursor = c->ring_cursor + 2; p.ring_done = (unsigned *)(c->ring_cursor + 3);
+        } else {
+            p.ring_also = c->ring_cursor + 2;          // no Refine launch: this one commits the frame and keeps the box cursor level
+        }
     }
     if (c->pipe_mark_fold) { p.mark = c->pipe_cnt + 2; p.mark_arrived = c->pipe_cnt + 4; }     // pipelined step: the tail's gate waits for this launch
     ProfScope ps(c, s, "decode", "decode", 0.0, (double)B * 30 * 625 * 4);
@@ -2504,6 +2555,7 @@ int smk_set_decode_params(smk_ctx *c, const float *anchor_wh, int n_anchor, int 
     if (stride > 0) c->anchor_stride = stride;
     c->penalty_k = penalty_k;
     c->window_influence = window_influence;
+    CHK(pipe_quiesce(c));
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);   // hp are baked into captured launches
     c->graphs.clear();
     c->graph_used.clear();
@@ -2527,7 +2579,8 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
     c->have_deferred_mask = false;
     c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
                         c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
-                        B <= 16;      // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
+                        (B <= 16 ||   // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
+                         (c->pipe_two && g_tune.pipe_two_form == 1));      // depth-2 pipelining: the tail's first part launches it (step_tail)
     int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, defer_mask_join, phase);
     c->defer_mask_req = false;
     CHK(rc2);
@@ -2544,12 +2597,22 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
 
 // the part nothing on the device waits for (tools/test.py:257-284: the mask is an output): Refine at the decoded positions
 // (+ the 63x63 mask head when the chain launch carries it) and the ring row's logits
-static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *refine_out, hipStream_t st) {
+static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *refine_out, hipStream_t st, int part = 0) {
     c->ring_in_step = c->ring_rows > 0;
     c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
-    int rcd = refine_out ? seq_refine(c, B, refine_out, st) : 0;
+    if (part == 1 && c->have_deferred_mask && g_tune.pipe_two_form == 1) {
+        // depth-2 pipelining: the 63x63 mask head FIRST (it needs head0 only) -- as its own launch beside the next frame's front end; inside
+        // the chain launch of part 2 its 640 tiles would take the CUs from that frame's conv_search (measured: 67 instead of 32 us,
+        // profiles/r05j_depth2_chain_mask_beside_heads.txt); the chain alone (one workgroup per stream) runs there for free
+        c->have_deferred_mask = false;
+        Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
+        ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
+        CHK(run_conv(c, "mask3", h0, nullptr, B, om, st));
+    }
+    int rcd = refine_out ? seq_refine(c, B, refine_out, st, part) : 0;
     c->ring_in_step = false;
     CHK(rcd);
+    if (part == 1) return 0;
     if (c->have_deferred_mask) {                 // the chain launch did not take it (timing aid on, ...): its own launch
         c->have_deferred_mask = false;
         Act h0 = act(c, "head0", 25, 25, 256 * nbranch(c));
@@ -2598,14 +2661,22 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     int64_t pk, wi;
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     const std::vector<const void *> io{x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi};
+    const bool graphs = c->graph_mode;
     const bool gate = g_tune.pipe_join != 0;
     const bool sig = gate && g_tune.pipe_sig == 1 && c->pipe_sig;
     const bool tgate = gate && g_tune.pipe_sig == 2;      // the tail's start is a gate kernel too (A/B)
     // where the main gate sits: in front of layer2 when that is the persistent sequence (it must own every CU), else in front of the
     // heads -- the first launches that write what the tail reads (smk_tune pipe_late = 0 keeps it in front of layer2 for the A/B)
     const bool late = gate && g_tune.pipe_late && !(seq_wanted(c, B) && !parallel_ok(c));
-    const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0) | (late ? 1 << 20 : 0);
-    const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io};
+    // depth 2 (the persistent sequence's batches, fp16 chain path, graph replay): the tail in TWO parts.  Part 1 (window convolutions,
+    // deconv, v*.2: everything that reads the kept features and the position) runs beside the next frame's front end as before; part 2
+    // (the Refine chain + the mask head: one low-occupancy launch of ~50 us that only reads part 1's outputs and head0) waits for the
+    // next frame's persistent launch to LEAVE and runs beside that frame's heads (conv_search / corr_head / decode leave 40-200 CUs
+    // idle) -- it is launched by the NEXT smk_step, or without its gate by whatever joins the pipeline first.
+    const bool two = c->pipe_depth >= 2 && graphs && gate && tgate && !late && !sig && refine_splittable(c, B) && !g_tune.pipe_eager;
+    const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0) | (late ? 1 << 20 : 0) | (two ? 1 << 21 : 0) |
+                   ((two && g_tune.pipe_two_form) ? 1 << 22 : 0);
+    const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io}, kt2g{13, B, fl, io}, kt2n{14, B, fl, io};
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
     auto main_ = [&](hipStream_t st) {
@@ -2616,34 +2687,57 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         }
         c->pipe_gate_late = late;           // ... else seq_track places it in front of the heads
         c->pipe_mark_fold = tgate;          // the decode launch's last writer is the main part's completion mark
+        c->pipe_two = two;
+        c->pipe_seq_exit = two; c->pipe_seq_exit_done = false;
         const int rcm = mid(st);
         c->pipe_mark_fold = false;
         c->pipe_gate_late = false;
+        c->pipe_two = false;
+        const bool exit_ok = c->pipe_seq_exit_done;
+        c->pipe_seq_exit = false;
         CHK(rcm);
+        if (two && !exit_ok && launch_pipe_done(c->pipe_cnt + 7, st)) return fail(SMK_E_HIP, "pipe_done launch failed");   // (no sequence launch took the mark)
         if (sig && launch_pipe_mark(c->pipe_sig, st)) return fail(SMK_E_HIP, "pipe_mark launch failed");
         return 0;
     };
-    auto tail = [&](hipStream_t st) {
-        if (tgate && launch_pipe_tail_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_tail_gate launch failed");
-        c->pipe_tail_fold = gate;           // a tail that ends in chain_mask_kernel lets its last workgroup be the "done" mark
+    // part: 0 = the whole tail (depth 1), 1 / 2 = its two parts (depth 2); gated: with the gate at its head
+    auto tail = [&](hipStream_t st, int part, bool gated) {
+        if (gated && tgate && launch_pipe_gate(c->pipe_cnt + (part == 2 ? 7 : 2), c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        c->pipe_tail_fold = gate && part == 0;      // a whole tail that ends in chain_mask_kernel lets its last workgroup be the "done" mark
         c->pipe_done_folded = false;
-        const int rct = step_tail(c, B, mask, box_out, refine_out, st);
+        const int rct = step_tail(c, B, mask, box_out, refine_out, st, part);
         c->pipe_tail_fold = false;
         CHK(rct);
-        if (gate && !c->pipe_done_folded && launch_pipe_done(c->pipe_cnt, st)) return fail(SMK_E_HIP, "pipe_done launch failed");
+        // what the next frame's main gate waits for: the whole tail (depth 1) / part 1 (depth 2: part 2 of the PREVIOUS frame precedes it in this stream)
+        if (gate && part != 2 && !c->pipe_done_folded && launch_pipe_done(c->pipe_cnt, st)) return fail(SMK_E_HIP, "pipe_done launch failed");
         return 0;
     };
-    const bool graphs = c->graph_mode;
-    const bool have = gate ? (c->graphs.count(km) && c->graphs.count(kt)) : (c->graphs.count(kf) && c->graphs.count(km) && c->graphs.count(kt));
+    bool have = c->graphs.count(km) && c->graphs.count(kt);
+    if (!gate) have = have && c->graphs.count(kf);
+    if (two) have = have && c->graphs.count(kt2g) && c->graphs.count(kt2n);
     if (graphs && !have) {
         // captured together: the middle part hands the mask head over to the tail at capture time
-        drop_graph(c, kf); drop_graph(c, km); drop_graph(c, kt);
+        drop_graph(c, kf); drop_graph(c, km); drop_graph(c, kt); drop_graph(c, kt2g); drop_graph(c, kt2n);
         if (gate) CHK(capture_graph(c, km, main_));
         else { CHK(capture_graph(c, kf, front)); CHK(capture_graph(c, km, mid)); }
-        c->pipe_tail_has_mask = c->have_deferred_mask;
-        CHK(capture_graph(c, kt, tail));
-        if (!(c->graphs.count(km) && c->graphs.count(kt))) return fail(SMK_E_STATE, "internal: pipelined step graphs evicted while capturing");
+        const bool hm = c->have_deferred_mask;
+        c->pipe_tail_has_mask = hm;
+        if (two) {
+            // (pipe_two_form 1: part 1 launches the mask head itself and part 2 is the bare chain; 0: the chain launch of part 2 carries it)
+            CHK(capture_graph(c, kt, [&](hipStream_t st) { return tail(st, 1, true); }));
+            c->have_deferred_mask = hm && g_tune.pipe_two_form == 0;
+            CHK(capture_graph(c, kt2g, [&](hipStream_t st) { return tail(st, 2, true); }));
+            c->have_deferred_mask = hm && g_tune.pipe_two_form == 0;
+            CHK(capture_graph(c, kt2n, [&](hipStream_t st) { return tail(st, 2, false); }));
+            c->have_deferred_mask = false;
+        } else {
+            CHK(capture_graph(c, kt, [&](hipStream_t st) { return tail(st, 0, true); }));
+        }
+        bool ok = c->graphs.count(km) && c->graphs.count(kt);
+        if (two) ok = ok && c->graphs.count(kt2g) && c->graphs.count(kt2n);
+        if (!ok) return fail(SMK_E_STATE, "internal: pipelined step graphs evicted while capturing");
     }
+    if (!two && c->tail2_pending) CHK(pipe_flush(c));       // (the mode changed under a pending second part: launch it now)
     if (gate) {
         CHK(graphs ? launch_graph(c, km, s) : main_(s));
         if (!graphs) c->seq_pending = true;
@@ -2669,11 +2763,21 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         HIPCHK(hipEventRecord(e_dec, s));
         HIPCHK(hipStreamWaitEvent(c->pipe_stream, e_dec, 0));
     }
-    if (graphs && !(g_tune.pipe_eager & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
+    if (two) {
+        // the side stream, in the order things happen on the device: [sequence of THIS frame has left] part 2 of the previous frame |
+        // [decode of this frame] part 1 of this frame.  Every step takes exactly one count of the "sequence has left" semaphore: with
+        // no part 2 pending (first step, or behind a flush) a bare gate does.
+        if (c->tail2_pending) CHK(launch_graph(c, c->tail2_gated_key, c->pipe_stream));
+        else if (launch_pipe_gate(c->pipe_cnt + 7, c->seq_err, c->seq_err_hdev, c->pipe_stream)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        CHK(launch_graph(c, kt, c->pipe_stream));
+        c->tail2_pending = true;
+        c->tail2_key = kt2n;
+        c->tail2_gated_key = kt2g;
+    } else if (graphs && !(g_tune.pipe_eager & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
     else {
         // (eager: the capture-time hand-over of the mask head is replayed from the context, see step_track_decode)
         if (graphs) c->have_deferred_mask = c->pipe_tail_has_mask;
-        CHK(tail(c->pipe_stream));
+        CHK(tail(c->pipe_stream, 0, true));
     }
     HIPCHK(hipEventRecord(e_tail, c->pipe_stream));
     c->tail_ev = e_tail;
@@ -2722,8 +2826,10 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
 
 int smk_set_pipeline(smk_ctx *c, int depth) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
-    if (depth < 0 || depth > 1) return fail(SMK_E_ARG, "smk_set_pipeline: depth %d (0 = off, 1 = one Refine / mask tail in flight)", depth);
+    if (depth < 0 || depth > 2)
+        return fail(SMK_E_ARG, "smk_set_pipeline: depth %d (0 = off, 1 = the tail beside the next frame's front end, 2 = its second part beside the next frame's heads)", depth);
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_quiesce(c));
     HIPCHK(hipDeviceSynchronize());
     c->tail_pending = false;
     if (depth > 0) {
@@ -2732,6 +2838,9 @@ int smk_set_pipeline(smk_ctx *c, int depth) {
             CHK(alloc_buf(c, "p1#1", c->buf_elems.at("p1")));
             CHK(alloc_buf(c, "p2#1", c->buf_elems.at("p2")));
         }
+        if (depth >= 2 && !c->buf.count("head0#1")) CHK(alloc_buf(c, "head0#1", c->buf_elems.at("head0")));
+        // (the box rows' own cursor of depth 2 starts where the shared one stands)
+        if (c->ring_cursor) HIPCHK(hipMemcpy(c->ring_cursor + 2, c->ring_cursor, sizeof(int), hipMemcpyDeviceToDevice));
         if (!c->pipe_stream) HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
         if (!c->pipe_cnt) HIPCHK(hipMalloc((void **)&c->pipe_cnt, 64));
         if (!c->pipe_sig) {
@@ -2756,11 +2865,20 @@ int smk_pipeline_join(smk_ctx *c, void *stream) {
     return pipe_join(c, (hipStream_t)stream, false);
 }
 
+int smk_pipeline_observe(smk_ctx *c, void *stream) {
+    if (!c) return fail(SMK_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->tail_pending) return 0;
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->tail_ev, 0));
+    return 0;
+}
+
 int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int rows, int batch) {
     if (!c) return fail(SMK_E_ARG, "ctx is NULL");
     if (rows < 0 || (rows > 0 && !box_ring)) return fail(SMK_E_ARG, "smk_set_result_ring: rows %d / box ring %p", rows, (void *)box_ring);
     if (rows > 0 && (batch < 1 || batch > c->maxB)) return fail(SMK_E_ARG, "smk_set_result_ring: batch %d not in [1,%d]", batch, c->maxB);
     HIPCHK(hipSetDevice(c->device));
+    CHK(pipe_quiesce(c));
     HIPCHK(hipDeviceSynchronize());
     c->tail_pending = false;
     // the captured step graphs carry the ring pointers (or no commit launch at all): start over
@@ -2768,8 +2886,8 @@ int smk_set_result_ring(smk_ctx *c, double *box_ring, void *refine_ring_f16, int
     c->graphs.clear();
     c->graph_used.clear();
     c->graph_has_seq.clear();
-    if (!c->ring_cursor) HIPCHK(hipMalloc((void **)&c->ring_cursor, 2 * sizeof(int)));
-    HIPCHK(hipMemset(c->ring_cursor, 0, 2 * sizeof(int)));
+    if (!c->ring_cursor) HIPCHK(hipMalloc((void **)&c->ring_cursor, 4 * sizeof(int)));
+    HIPCHK(hipMemset(c->ring_cursor, 0, 4 * sizeof(int)));
     c->ring_box = rows ? box_ring : nullptr;
     c->ring_ref = rows ? refine_ring_f16 : nullptr;
     c->ring_rows = rows;
@@ -2783,7 +2901,7 @@ int smk_result_ring_cursor(smk_ctx *c, int *frames_out, int reset, void *stream)
     CHK(pipe_join(c, (hipStream_t)stream, true));        // the cursor is advanced by the tail of the last pipelined step
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (frames_out) HIPCHK(hipMemcpy(frames_out, c->ring_cursor, sizeof(int), hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(c->ring_cursor, 0, 2 * sizeof(int)));
+    if (reset) HIPCHK(hipMemset(c->ring_cursor, 0, 4 * sizeof(int)));
     return 0;
 }
 

@@ -568,6 +568,7 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
             if (prev == (unsigned)p.B - 1) {
                 __hip_atomic_store(p.ring_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(p.ring_cursor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (p.ring_also) __hip_atomic_fetch_add(p.ring_also, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -648,9 +649,10 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
 // polls, it holds one wave slot beside the next frame's kernels -- no deadlock.  A partner that does not arrive within 0.2 s raises the
 // sequence failure flag (code 3): the caller re-submits, as for a barrier time-out.
 // Both joins are SEMAPHORES with one consumer each: P = poll until the count is positive, then take one; V = add one.
-//   sem_tail (cnt[0], starts at 1): V by the tail's end (pipe_done_kernel, or chain_mask_kernel's last workgroup), P by the gate in
-//       front of the next frame's persistent launch;
-//   sem_main (cnt[2], starts at 0): V by the decode launch's last writer (or pipe_mark_kernel), P by the gate at the head of the tail.
+//   sem_tail (cnt[0], starts at 1): V by the tail's end (pipe_done_kernel, or chain_mask_kernel's last workgroup; depth 2: by the end of the
+//       tail's FIRST part), P by the gate in front of the next frame's persistent launch (outside its batches: in front of the heads);
+//   sem_main (cnt[2], starts at 0): V by the decode launch's last writer, P by the gate at the head of the tail;
+//   sem_seq  (cnt[7], starts at 0; depth 2): V by conv_seq_kernel's last leaving team, P by the gate at the head of the tail's second part.
 __device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(sem, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -663,22 +665,14 @@ __device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_hos
     }
     __hip_atomic_fetch_sub(sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *cnt, int *err, int *err_host) {
-    if (threadIdx.x == 0) pipe_sem_p(cnt, err, err_host);
+// one wave, 8 VGPRs, no LDS: a gate that polls THROUGH another stream's kernels (the tail's gate is resident while the next frame's
+// persistent launch runs) must fit beside a conv_seq_kernel workgroup -- 2 x 248 of a SIMD's 512 VGPRs.  If it ever did not, the
+// persistent launch would not get its CU, decode would never run, and the gates' 0.2 s limits raise the failure flag (loud, no hang).
+__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *sem, int *err, int *err_host) {
+    if (threadIdx.x == 0) pipe_sem_p(sem, err, err_host);
 }
-__global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *cnt) {
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the tail's START as a gate as well (smk_tune pipe_sig = 2, the default): one wave at the head of the tail graph.  It becomes resident as
-// soon as the previous tail has drained, i.e. it polls THROUGH the next frame's persistent launch and must fit beside a
-// conv_seq_kernel workgroup: one wave, 8 VGPRs, no LDS against that kernel's 2 x 248 of a SIMD's 512 VGPRs -- if it ever did not, the
-// persistent launch would not get its CU, decode would never run, and both gates' 0.2 s limits raise the failure flag (loud, no hang).
-__global__ __launch_bounds__(64) void pipe_tail_gate_kernel(unsigned *cnt, int *err, int *err_host) {
-    if (threadIdx.x == 0) pipe_sem_p(cnt + 2, err, err_host);
-}
-int launch_pipe_tail_gate(unsigned *cnt, int *err, int *err_host, void *stream) {
-    hipLaunchKernelGGL(pipe_tail_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt, err, err_host);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+__global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *sem) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sem, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // (smk_tune pipe_sig = 1: the main part's completion mark in SIGNAL memory for a hipStreamWaitValue32 on the side stream -- 3-4 us in
 //  the two-kernel probe, +50 % per step in the real loop: kept as the measured alternative, profiles/r05e_pipe_sig_ab.txt)
@@ -689,12 +683,12 @@ int launch_pipe_mark(unsigned *sig, void *stream) {
     hipLaunchKernelGGL(pipe_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sig);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_pipe_gate(unsigned *cnt, int *err, int *err_host, void *stream) {
-    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt, err, err_host);
+int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream) {
+    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sem, err, err_host);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_pipe_done(unsigned *cnt, void *stream) {
-    hipLaunchKernelGGL(pipe_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cnt);
+int launch_pipe_done(unsigned *sem, void *stream) {
+    hipLaunchKernelGGL(pipe_done_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sem);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -142,6 +142,8 @@ struct SeqArgs {
     unsigned long long *clk;   // optional [2 * SEQ_MAX + 1]: 100 MHz timestamps of (team 0, slot 0): start, then per layer
                                //   (tiles done, barrier passed) -- measurement aid (SMK_SEQ_CLK=1)
     unsigned long long *clk2;  // optional [8 * SEQ_MAX] (SMK_SEQ_CLK=2): per layer, the phases of (team 0, slot 0)'s first tile, see wreg_tile
+    unsigned *exit_sem;        // optional (pipelined frame step, depth 2): the last team to leave adds one to exit_sem[0] (a semaphore the tail's second
+                               //   part waits on); exit_sem[1] counts the teams that have left (zero between launches)
     SeqLayer L[SEQ_MAX];
 };
 static_assert(sizeof(SeqArgs) <= 4096, "the layer list travels in the kernel-argument segment");
@@ -216,6 +218,8 @@ struct Tuning {
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
+    int pipe_two_form = 1;     // depth-2 pipelining: 1 = the mask head as its own launch at the head of the tail's first part, the bare Refine chain beside
+                               // the next frame's heads; 0 = chain + mask head as one launch beside the heads (measured: it starves conv_search)
     int pipe_late = 1;         // pipelined frame step outside the persistent sequence's batches: the main gate in front of the heads instead of in front of
                                // layer2 (the tail overlaps the whole backbone of the next frame; p2 exists twice as well)
     int pipe_sig = 2;          // pipelined frame step, how the side stream learns that decode(f) is done: 2 (default) = a one-wave gate kernel at the head of
@@ -332,6 +336,7 @@ struct DecodeParams {
     int *ring_cursor;
     unsigned *ring_done;
     int ring_rows, ring_advance;
+    int *ring_also;          // a second cursor advanced together with ring_cursor (the engine keeps a box-row cursor and a frames-committed cursor), or nullptr
     // pipelined frame step: the last stream's writer adds one to *mark (the semaphore the tail's gate waits on); mark_arrived counts streams
     unsigned *mark, *mark_arrived;
 };
@@ -436,9 +441,8 @@ int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
 int launch_ring_commit(const RingParams &p, void *stream);
 // pipelined frame steps: in-stream gate (waits for the previous frame's tail) / the tail's completion mark; cnt = device [2] u32
-int launch_pipe_gate(unsigned *cnt, int *err, int *err_host, void *stream);
-int launch_pipe_done(unsigned *cnt, void *stream);
-int launch_pipe_tail_gate(unsigned *cnt, int *err, int *err_host, void *stream);     // (smk_tune pipe_sig = 2)
+int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream);     // P: poll until *sem > 0, take one
+int launch_pipe_done(unsigned *sem, void *stream);                             // V
 int launch_pipe_mark(unsigned *sig, void *stream);          // sig: signal memory (hipMallocSignalMemory), waited for with hipStreamWaitValue32
 int launch_crop_resize(const CropParams &p, int B, void *stream);
 int launch_paste_mask(const PasteParams &p, int B, void *stream);

@@ -494,16 +494,19 @@ class Custom(nn.Module):
         track_step's box is.  Bit-identical to the serial step."""
         if self._ctx is None:
             raise RuntimeError("set_pipeline(): run template() first")
-        _lib.check(_lib.lib().smk_set_pipeline(self._ctx, 1 if on else 0))
-        self._pipeline = bool(on)
+        depth = int(on)           # True = 1; 2 = throughput mode: the Refine chain + mask head of frame f beside the heads of frame f + 1
+        _lib.check(_lib.lib().smk_set_pipeline(self._ctx, depth))
+        self._pipeline = depth
 
-    def pipeline_join(self, stream=None):
+    def pipeline_join(self, stream=None, launch_pending=True):
         """Order ``stream`` (default: the current stream) behind the outstanding Refine / mask tail of the last pipelined
-        track_step; a no-op when there is none."""
+        track_step; a no-op when there is none.  launch_pending=False (depth 2): only behind what has been launched so far --
+        the second part of the last frame's tail keeps waiting for the next track_step (smk_pipeline_observe)."""
         if self._ctx is None:
             return
         sp = _lib.current_stream_ptr() if stream is None else ctypes.c_void_p(stream.cuda_stream)
-        _lib.check(_lib.lib().smk_pipeline_join(self._ctx, sp))
+        fn = _lib.lib().smk_pipeline_join if launch_pending else _lib.lib().smk_pipeline_observe
+        _lib.check(fn(self._ctx, sp))
 
     def result_ring_frames(self, reset=False):
         """frames committed to the ring so far (synchronises the current stream)"""

@@ -30,11 +30,13 @@ def _inputs(B, n, seed):
     return z, xs, twh
 
 
-@pytest.mark.parametrize("B,dtype,frames", [(8, "f16", 7), (64, "f16", 4), (1, "f16", 5), (8, "f32", 3), (3, "f16", 4)])
-def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
-    """ring rows (box f64 + fp16 Refine logits) and the step's own outputs, frame by frame, serial vs pipelined -- B = 8 runs
-    layer2 .. adjust as the persistent sequence (which waits for the tail), B = 64 / 1 / 3 the per-launch kernels, fp32 ends
-    its Refine in the stand-alone ring commit launch"""
+@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("B,dtype,frames", [(8, "f16", 7), (64, "f16", 4), (1, "f16", 5), (8, "f32", 3), (3, "f16", 4), (16, "f16", 4), (24, "f16", 3)])
+def test_pipelined_rows_equal_serial_rows(B, dtype, frames, depth):
+    """ring rows (box f64 + fp16 Refine logits) and the step's own outputs, frame by frame, serial vs pipelined -- B = 8 / 16 / 24 run
+    layer2 .. adjust as the persistent sequence (which waits for the tail; depth 2 cuts the tail in two there, B = 24 without the
+    mask head in the chain launch), B = 64 / 1 / 3 the per-launch kernels (main gate in front of the heads), fp32 ends its Refine in
+    the stand-alone ring commit launch"""
     m = _model(B, dtype)
     z, xs, twh = _inputs(B, frames, 500 + B)
     m.template(z)
@@ -48,11 +50,12 @@ def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
     assert m.result_ring_frames(reset=True) == frames
     box.zero_(); ref.zero_()
 
-    m.set_pipeline(True)
+    m.set_pipeline(depth)
     got = []
     for i, x in enumerate(xs):
         o = m.track_step(x, twh, refine=True, stage=False)
-        # box / cls / loc of THIS frame are complete in stream order; refine / mask behind the join
+        # box / cls / loc of THIS frame are complete in stream order; refine / mask behind the join (depth 2: which launches the
+        # second part of the tail without its gate)
         cur = {k: o[k].clone() for k in ("box", "cls", "loc")}
         m.pipeline_join()
         cur.update({k: o[k].clone() for k in ("refine", "mask")})
@@ -75,12 +78,26 @@ def test_pipelined_rows_equal_serial_rows(B, dtype, frames):
     assert m.result_ring_frames() == frames
     assert torch.equal(box, want_box)
     assert torch.equal(ref, want_ref)
+    # ... and the step's own output buffers hold the LAST frame's results behind the join
+    m.pipeline_join()
+    torch.cuda.synchronize()
+    for k in ("refine", "mask"):
+        assert torch.equal(o[k], outs[-1][k]), k
+    # mixed forms on one ring: serial, pipelined, without Refine -- both ring cursors advance once per frame whatever the form
+    assert m.result_ring_frames(reset=True) == frames
+    m.track_step(xs[0], twh, refine=True, stage=False)
+    m.set_pipeline(0)
+    m.track_step(xs[1], twh, refine=True, stage=False)
+    m.set_pipeline(depth)
+    m.track_step(xs[2], twh, refine=True, stage=False)
+    assert m.result_ring_frames() == 3
+    assert torch.equal(box[:3], want_box[:3]) and torch.equal(ref[:3], want_ref[:3])
 
     # serial entry points behind a pipelined step: they join the tail and see that frame's features
     o = m.track_step(xs[0], twh, refine=True, stage=False)
     pos = torch.tensor([[12, 12]] * B, dtype=torch.int32).cuda()
     r1 = m.track_refine(pos).clone()
-    m.set_pipeline(False)
+    m.set_pipeline(0)
     m.track_step(xs[0], twh, refine=True, stage=False)
     r0 = m.track_refine(pos).clone()
     torch.cuda.synchronize()
@@ -96,20 +113,22 @@ def test_other_join_forms_are_the_same_arithmetic(knobs):
     old = {k: _lib.tune_get(k) for k in knobs}
     try:
         _lib.tune(**knobs)
-        test_pipelined_rows_equal_serial_rows(8, "f16", 5)
+        test_pipelined_rows_equal_serial_rows(8, "f16", 5, 2 if "pipe_eager" in knobs else 1)
     finally:
         _lib.tune(**old)
 
 
-def test_pipelined_200_steps_clean_and_deterministic():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_pipelined_200_steps_clean_and_deterministic(depth):
     """200 free-running pipelined steps at the bench configuration: the persistent sequence never reports a failure (it waits
-    for the tail, so it still owns every CU), the frame counter arrives at 200, and the last rows equal a second run's"""
+    for the tail, so it still owns every CU -- with the tail's gate wave resident beside it), the frame counter arrives at 200, and
+    the last rows equal a second run's"""
     B, rows = 8, 4
     m = _model(B)
     z, xs, twh = _inputs(B, 4, 900)
     m.template(z)
     box, ref = m.set_result_ring(rows, batch=B)
-    m.set_pipeline(True)
+    m.set_pipeline(depth)
     snaps = []
     for rep in range(2):
         for i in range(200):
