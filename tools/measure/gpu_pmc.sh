@@ -2,7 +2,10 @@
 # PMC passes (separate runs, kernel-trace only -- never with sys/hip traces) for the bench step.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/pmc
 rocprofv3 -L > gpurun_out/pmc/counters_list.txt 2>&1
-CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-also --prewarm-seconds 0.3 ${WL:+--workload $WL}"
+# --serial: counter collection serialises the dispatches of ALL queues, which the pipelined step's gate kernels cannot survive (a gate waits
+# for a kernel of the other queue that the profiler will not start before the gate ends: 0.2 s time-outs, the persistent launches behind the
+# raised flag return at once and pollute every per-kernel average -- seen in round 5's first final run: 159 MB "per launch" instead of 647)
+CMD="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-also --no-long --serial --prewarm-seconds 0.3 ${WL:+--workload $WL}"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for SET in "$@"; do
