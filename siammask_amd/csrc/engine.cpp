@@ -1159,6 +1159,8 @@ static int seq_health(smk_ctx *c) {
     (void)hipDeviceSynchronize();                        // launches that found the flag set returned at once
     c->seq_fail = e;
     if (e != 3) c->seq_grid = 0;                         // (3: the pipelined step's gate timed out -- nothing wrong with the sequences)
+    else c->pipe_depth = 0;                              // ... but something serialises this context's two queues (a counter-collecting profiler
+                                                         // does): frame steps are serial from here on (smk_set_pipeline turns it back on)
     if (c->pipe_cnt) {                                   // the pipelined step's semaphores at rest (see pipe_reset_counters)
         const unsigned init[16] = {1u, 0u};
         (void)hipMemcpy(c->pipe_cnt, init, sizeof(init), hipMemcpyHostToDevice);
@@ -1177,9 +1179,10 @@ static int seq_health(smk_ctx *c) {
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
     if (e == 3)
-        return fail(SMK_E_SEQ, "conv_seq_kernel reported: (pipelined step) the Refine / mask tail of the previous frame did not finish within 0.2 s "
-                    "of the next frame's front end; the results of the calls enqueued on this context since then are invalid (the cached "
-                    "template included): call template() again and re-submit the frame");
+        return fail(SMK_E_SEQ, "conv_seq_kernel reported: (pipelined step) a gate waited 0.2 s for its partner on the other stream -- something serialises "
+                    "the two queues of this context (a profiler collecting counters does); the results of the calls enqueued on this context "
+                    "since then are invalid (the cached template included) and frame steps are serial from here on: call template() again and "
+                    "re-submit the frame");
     return fail(SMK_E_SEQ, "conv_seq_kernel reported %s: the results of the calls enqueued on this context since then are invalid "
                 "(the cached template included); persistent sequences are now off for this context (per-layer kernels from here "
                 "on): call template() again and re-submit the frame",

@@ -141,6 +141,32 @@ def test_pipelined_200_steps_clean_and_deterministic(depth):
     assert m.seq_recovered == 0
 
 
+def test_gate_timeout_is_loud_and_leaves_serial_steps_behind():
+    """a gate that waits 0.2 s for its partner (a profiler that serialises the two queues produces exactly this) raises failure code 3: the
+    next entry point returns SMK_E_SEQ, the context goes back to serial steps, and after template() the frames are right again -- here the
+    flag is raised by hand"""
+    B = 8
+    m = _model(B)
+    z, xs, twh = _inputs(B, 2, 950)
+    m.template(z)
+    want = {k: v.clone() for k, v in m.track_step(xs[0], twh, refine=True, stage=False).items() if v is not None}
+    torch.cuda.synchronize()
+    m.set_pipeline(1)
+    m.track_step(xs[1], twh, refine=True, stage=False)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().smk_debug_seq_inject(m._ctx, 3))
+    with pytest.raises(_lib.SmkError) as ei:
+        m.track_step(xs[0], twh, refine=True, stage=False)
+    assert ei.value.code == _lib.E_SEQ and "gate" in str(ei.value)
+    m.template(z)
+    o = m.track_step(xs[0], twh, refine=True, stage=False)       # serial now (the library switched pipelining off)
+    torch.cuda.synchronize()                                     # (no join needed)
+    for k in want:
+        assert torch.equal(o[k], want[k]), k
+    g, e = m.seq_status()
+    assert g > 0                                                 # the persistent sequence itself is still in use
+
+
 def test_ring_batch_is_recorded_by_the_library():
     """a C caller that sets a ring for one batch and steps another one must get SMK_E_ARG, not rows
     written past the ring"""
