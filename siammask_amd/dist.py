@@ -114,7 +114,9 @@ class ResultGather(object):
     runs on a dedicated side stream; ``wait()`` makes the current stream wait for it.
 
     The inputs must be PRIVATE result buffers (bench.py's Results rows), not the views `track_step` returns: those
-    alias the persistent graph I/O buffers, which the next frame overwrites while the side-stream gather still reads."""
+    alias the persistent graph I/O buffers, which the next frame overwrites while the side-stream gather still reads.
+    With pipelined frame steps (Custom.set_pipeline) call ``model.pipeline_join()`` on the current stream first: the last
+    frame's logits row is written by the pipeline's side stream, which torch does not know about."""
 
     def __init__(self, device=None, always_collective=False):
         self.device = device
