@@ -5,8 +5,8 @@ cp $F/kernel_sources_sha256.txt profiles/r05_kernel_sources_sha256.txt
 cp $F/source_commit.txt profiles/r05_source_commit.txt
 cp $F/pytest_gpu.txt profiles/r05_pytest_gpu.txt; cp $F/smoke.txt profiles/r05_smoke.txt
 cp $F/pmc_calibration.json profiles/pmc_calibration.json
-cp $P/pmc_by_kernel.json profiles/r05_pmc_by_kernel.json
-cp $P/pmc_traffic_sharp_b8_f16.json profiles/pmc_traffic_sharp_b8_f16.json
+cp $F/pmc_by_kernel.json profiles/r05_pmc_by_kernel.json
+cp $F/pmc_traffic_sharp_b8_f16.json profiles/pmc_traffic_sharp_b8_f16.json
 cp $F/rocprofv3_kernel_stats_sharp_b8_f16.json profiles/rocprofv3_kernel_stats_sharp_b8_f16.json
 cp $F/rocprofv3_kernel_stats_sharp_b8_f16.csv profiles/r05_rocprofv3_kernel_stats.csv
 cp $F/rocprofv3_kernel_stats_sharp_b8_f32.csv profiles/r05_rocprofv3_kernel_stats_f32.csv
