@@ -59,6 +59,9 @@ __global__ __launch_bounds__(CH_NT) void corr_head_kernel(const CorrHeadParams p
     const int fm = lane & 31, fh = lane >> 5;
     const int Cs = p.Cs;
     const size_t opix0 = (size_t)b * (CH_WO * CH_WO) + band * CH_PIX;      // first output pixel of the band
+    // pipelined frame step, depth 2: this launch STARTING means conv_search has drained -- the first workgroup tells the previous frame's
+    // Refine chain + mask head launch (its gate polls this semaphore) that the chip's idle CUs are its own from here on
+    if (p.start_sem && tid == 0 && band == 0 && br == 0 && b == 0) __hip_atomic_fetch_add(p.start_sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- phase 1: the correlation, two rounds of 128 channels -------------------------------------------------------------------
     const _Float16 *xs = p.xs + ((size_t)(b * CH_W + band * CH_BR) * CH_W) * Cs + br * 256;      // the band's 261 input pixels are contiguous

@@ -319,6 +319,7 @@ struct smk_ctx {
     unsigned *pipe_cnt = nullptr;    // device [16] u32: [0] semaphore "tails completed" (starts at 1), [2] semaphore "main parts completed",
                                      // [4] / [5] arrival counters of decode's streams / chain_mask's workgroups (misc_kernels.hip pipe_*)
     bool pipe_two = false;           // (recording a depth-2 pipelined step) decode keeps its own ring cursor
+    bool pipe_corr_sem = false;      // ... or corr_head's first workgroup does (form 2)
     bool pipe_seq_exit = false, pipe_seq_exit_done = false;   // ... and the sequence launch raises the "chip is free" semaphore when it leaves
     bool tail2_pending = false;      // depth 2: the second part of the last frame's tail (chain + mask head) has not been launched yet
     GraphKey tail2_key, tail2_gated_key;   // ... its graph without / with the gate (flush form / the form the next step launches)
@@ -1671,6 +1672,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
             hp.w3_bytes[0] = (unsigned)((size_t)ic->second.rows * ic->second.Kpad * 2);
             hp.w3_bytes[1] = (unsigned)((size_t)il->second.rows * il->second.Kpad * 2);
             hp.B = B; hp.nb = nb; hp.Cs = 256 * nbt;
+            if (c->pipe_corr_sem) { hp.start_sem = c->pipe_cnt + 7; c->pipe_seq_exit_done = true; }
             const double flop = 2.0 * B * nb * 256.0 * 625 * 25 + 2.0 * B * nb * 625.0 * 256 * 256 + 2.0 * B * 625.0 * 256 * 30;
             const double bytes = (double)B * nb * 256.0 * (29 * 29 + 25 + 2 * 625) * 2 + 3.0 * 256 * 256 * 2 + (double)B * 30 * 625 * 4;
             ProfScope ps(c, s, "dw_xcorr+head0+cls3+loc3", "corr_head", flop, bytes);
@@ -2425,7 +2427,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
     else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
-    else if (!strcmp(key, "pipe_two_form")) g_tune.pipe_two_form = value != 0;
+    else if (!strcmp(key, "pipe_two_form")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_two_form 0..2"); g_tune.pipe_two_form = value; }
     else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
@@ -2583,7 +2585,7 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
     c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
                         c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
                         (B <= 16 ||   // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
-                         (c->pipe_two && g_tune.pipe_two_form == 1));      // depth-2 pipelining: the tail's first part launches it (step_tail)
+                         (c->pipe_two && g_tune.pipe_two_form == 1));      // depth-2 pipelining, form 1: the tail's first part launches it (step_tail)
     int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, defer_mask_join, phase);
     c->defer_mask_req = false;
     CHK(rc2);
@@ -2678,7 +2680,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     // idle) -- it is launched by the NEXT smk_step, or without its gate by whatever joins the pipeline first.
     const bool two = c->pipe_depth >= 2 && graphs && gate && tgate && !late && !sig && refine_splittable(c, B) && !g_tune.pipe_eager;
     const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0) | (late ? 1 << 20 : 0) | (two ? 1 << 21 : 0) |
-                   ((two && g_tune.pipe_two_form) ? 1 << 22 : 0);
+                   ((two && g_tune.pipe_two_form == 1) ? 1 << 22 : 0) | ((two && g_tune.pipe_two_form == 2) ? 1 << 23 : 0);
     const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io}, kt2g{13, B, fl, io}, kt2n{14, B, fl, io};
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
@@ -2691,8 +2693,11 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         c->pipe_gate_late = late;           // ... else seq_track places it in front of the heads
         c->pipe_mark_fold = tgate;          // the decode launch's last writer is the main part's completion mark
         c->pipe_two = two;
-        c->pipe_seq_exit = two; c->pipe_seq_exit_done = false;
+        // the "chip is free for the previous frame's second tail part" semaphore: raised by the persistent launch's last leaving team
+        // (forms 0 / 1) or by corr_head's first workgroup, i.e. behind conv_search (form 2)
+        c->pipe_seq_exit = two && g_tune.pipe_two_form != 2; c->pipe_corr_sem = two && g_tune.pipe_two_form == 2; c->pipe_seq_exit_done = false;
         const int rcm = mid(st);
+        c->pipe_corr_sem = false;
         c->pipe_mark_fold = false;
         c->pipe_gate_late = false;
         c->pipe_two = false;
@@ -2728,9 +2733,9 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         if (two) {
             // (pipe_two_form 1: part 1 launches the mask head itself and part 2 is the bare chain; 0: the chain launch of part 2 carries it)
             CHK(capture_graph(c, kt, [&](hipStream_t st) { return tail(st, 1, true); }));
-            c->have_deferred_mask = hm && g_tune.pipe_two_form == 0;
+            c->have_deferred_mask = hm && g_tune.pipe_two_form != 1;
             CHK(capture_graph(c, kt2g, [&](hipStream_t st) { return tail(st, 2, true); }));
-            c->have_deferred_mask = hm && g_tune.pipe_two_form == 0;
+            c->have_deferred_mask = hm && g_tune.pipe_two_form != 1;
             CHK(capture_graph(c, kt2n, [&](hipStream_t st) { return tail(st, 2, false); }));
             c->have_deferred_mask = false;
         } else {

@@ -219,7 +219,8 @@ struct Tuning {
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
     int pipe_two_form = 1;     // depth-2 pipelining: 1 = the mask head as its own launch at the head of the tail's first part, the bare Refine chain beside
-                               // the next frame's heads; 0 = chain + mask head as one launch beside the heads (measured: it starves conv_search)
+                               // the next frame's heads; 0 = chain + mask head as one launch beside the heads (measured: it starves conv_search);
+                               // 2 = chain + mask head as one launch behind conv_search (beside corr_head + decode: 136-216 idle CUs)
     int pipe_late = 1;         // pipelined frame step outside the persistent sequence's batches: the main gate in front of the heads instead of in front of
                                // layer2 (the tail overlaps the whole backbone of the next frame; p2 exists twice as well)
     int pipe_sig = 2;          // pipelined frame step, how the side stream learns that decode(f) is done: 2 (default) = a one-wave gate kernel at the head of
@@ -303,6 +304,7 @@ struct CorrHeadParams {
     int n3[2];
     unsigned w0_bytes, w3_bytes[2];
     int B, nb, Cs;
+    unsigned *start_sem;       // optional: a semaphore raised once when the launch starts (pipelined frame step, depth 2)
 };
 int launch_corr_head(const CorrHeadParams &p, void *stream);
 

@@ -104,16 +104,17 @@ def test_pipelined_rows_equal_serial_rows(B, dtype, frames, depth):
     assert torch.equal(r0, r1)
 
 
-@pytest.mark.parametrize("knobs", [dict(pipe_join=0), dict(pipe_sig=0), dict(pipe_sig=1), dict(pipe_eager=2)])
+@pytest.mark.parametrize("knobs", [dict(pipe_join=0), dict(pipe_sig=0), dict(pipe_sig=1), dict(pipe_eager=2), dict(pipe_two_form=0), dict(pipe_two_form=2)])
 def test_other_join_forms_are_the_same_arithmetic(knobs):
     """the measured alternatives of the two joins, kept for the A/B (profiles/r05a_*, r05e_*, r05f_*): pipe_join = 0 -- three graphs and
     a cross-queue event wait instead of the in-stream gate kernel; pipe_sig = 0 -- the tail's start by event record + wait instead
     of the gate that polls beside the persistent launch; pipe_sig = 1 -- hipStreamWaitValue32 on signal memory; pipe_eager = 2 -- the
-    tail as eager launches.  Same rows."""
+    tail as eager launches; pipe_two_form = 0 / 2 -- depth 2 with chain + mask head as ONE launch behind the persistent launch /
+    behind conv_search (profiles/r05j_*, r05o_*).  Same rows."""
     old = {k: _lib.tune_get(k) for k in knobs}
     try:
         _lib.tune(**knobs)
-        test_pipelined_rows_equal_serial_rows(8, "f16", 5, 2 if "pipe_eager" in knobs else 1)
+        test_pipelined_rows_equal_serial_rows(8, "f16", 5, 2 if ("pipe_eager" in knobs or "pipe_two_form" in knobs) else 1)
     finally:
         _lib.tune(**old)
 
