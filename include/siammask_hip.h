@@ -147,7 +147,11 @@ int smk_step(smk_ctx *ctx, const float *x_dev, int batch, int flags, const doubl
  * sized for (ABI 1.5: recorded; an smk_step with another batch fails with SMK_E_ARG instead of writing past the rows).
  * refine_ring_f16 may be NULL (boxes only); rows = 0 switches the ring off.  Synchronises the device
  * and drops the captured graphs.  smk_result_ring_cursor synchronises `stream` (behind an outstanding pipelined tail), returns
- * the number of frames committed (mod 2^32) and optionally resets it. */
+ * the number of frames committed (mod 2^32) and optionally resets it.
+ * A frame whose persistent sequence launch FAILED (SMK_E_SEQ from the next entry point / smk_seq_sync_check) has still committed a
+ * row -- of invalid values -- and advanced the counter: the caller that re-submits the frame either resets the counter
+ * (smk_result_ring_cursor(.., reset = 1)) and re-runs from the last frame it trusts, or overwrites by position: the re-submitted frame
+ * lands in the NEXT row.  The library does not rewind the cursor (rows may already have been handed to a gather). */
 int smk_set_result_ring(smk_ctx *ctx, double *box_ring_dev, void *refine_ring_f16_dev, int rows, int batch);
 int smk_result_ring_cursor(smk_ctx *ctx, int *frames_out, int reset, void *stream);
 
