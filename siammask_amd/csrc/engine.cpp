@@ -1180,7 +1180,7 @@ static int seq_health(smk_ctx *c) {
     c->template_B = 0;                                   // nothing says the cached template features were computed before the failure
     c->track_B = 0;
     if (e == 3)
-        return fail(SMK_E_SEQ, "conv_seq_kernel reported: (pipelined step) a gate waited 0.2 s for its partner on the other stream -- something serialises "
+        return fail(SMK_E_SEQ, "conv_seq_kernel reported: (pipelined step) a gate waited 0.2 s (a tail's gate: 5 s) for its partner on the other stream -- something serialises "
                     "the two queues of this context (a profiler collecting counters does); the results of the calls enqueued on this context "
                     "since then are invalid (the cached template included) and frame steps are serial from here on: call template() again and "
                     "re-submit the frame");
@@ -2710,7 +2710,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     };
     // part: 0 = the whole tail (depth 1), 1 / 2 = its two parts (depth 2); gated: with the gate at its head
     auto tail = [&](hipStream_t st, int part, bool gated) {
-        if (gated && tgate && launch_pipe_gate(c->pipe_cnt + (part == 2 ? 7 : 2), c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        if (gated && tgate && launch_pipe_gate(c->pipe_cnt + (part == 2 ? 7 : 2), c->seq_err, c->seq_err_hdev, st, 1)) return fail(SMK_E_HIP, "pipe_gate launch failed");
         c->pipe_tail_fold = gate && part == 0;      // a whole tail that ends in chain_mask_kernel lets its last workgroup be the "done" mark
         c->pipe_done_folded = false;
         const int rct = step_tail(c, B, mask, box_out, refine_out, st, part);
@@ -2776,7 +2776,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         // [decode of this frame] part 1 of this frame.  Every step takes exactly one count of the "sequence has left" semaphore: with
         // no part 2 pending (first step, or behind a flush) a bare gate does.
         if (c->tail2_pending) CHK(launch_graph(c, c->tail2_gated_key, c->pipe_stream));
-        else if (launch_pipe_gate(c->pipe_cnt + 7, c->seq_err, c->seq_err_hdev, c->pipe_stream)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        else if (launch_pipe_gate(c->pipe_cnt + 7, c->seq_err, c->seq_err_hdev, c->pipe_stream, 1)) return fail(SMK_E_HIP, "pipe_gate launch failed");
         CHK(launch_graph(c, kt, c->pipe_stream));
         c->tail2_pending = true;
         c->tail2_key = kt2n;

@@ -653,11 +653,15 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
 //       tail's FIRST part), P by the gate in front of the next frame's persistent launch (outside its batches: in front of the heads);
 //   sem_main (cnt[2], starts at 0): V by the decode launch's last writer, P by the gate at the head of the tail;
 //   sem_seq  (cnt[7], starts at 0; depth 2): V by conv_seq_kernel's last leaving team, P by the gate at the head of the tail's second part.
-__device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host) {
+// `limit` (100 MHz ticks): the MAIN gate waits for a tail that was enqueued on a free side stream a frame ago -- bounded by the tail's own
+// run time, 0.2 s is generous.  A gate at the head of a TAIL starts polling as soon as the side stream is free, i.e. possibly long before
+// the step it belongs to even starts on the caller's stream (whatever the caller enqueued in front of the step runs first): its limit is
+// 5 s -- long enough for any sane stream, short enough that a lost partner never hangs the device for good.
+__device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host, unsigned long long limit) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(sem, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {          // 100 MHz: 0.2 s
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
             __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;                                                          // (the count is left alone: the host resets it)
@@ -668,8 +672,8 @@ __device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_hos
 // one wave, 8 VGPRs, no LDS: a gate that polls THROUGH another stream's kernels (the tail's gate is resident while the next frame's
 // persistent launch runs) must fit beside a conv_seq_kernel workgroup -- 2 x 248 of a SIMD's 512 VGPRs.  If it ever did not, the
 // persistent launch would not get its CU, decode would never run, and the gates' 0.2 s limits raise the failure flag (loud, no hang).
-__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *sem, int *err, int *err_host) {
-    if (threadIdx.x == 0) pipe_sem_p(sem, err, err_host);
+__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *sem, int *err, int *err_host, unsigned long long limit) {
+    if (threadIdx.x == 0) pipe_sem_p(sem, err, err_host, limit);
 }
 __global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *sem) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(sem, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -683,8 +687,9 @@ int launch_pipe_mark(unsigned *sig, void *stream) {
     hipLaunchKernelGGL(pipe_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sig);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream) {
-    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sem, err, err_host);
+int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream, int long_wait) {
+    hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sem, err, err_host,
+                       long_wait ? 500000000ull : 20000000ull);             // 5 s / 0.2 s at 100 MHz
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_pipe_done(unsigned *sem, void *stream) {

@@ -142,6 +142,35 @@ def test_pipelined_200_steps_clean_and_deterministic(depth):
     assert m.seq_recovered == 0
 
 
+def test_a_slow_stream_in_front_of_the_step_is_not_a_gate_timeout():
+    """the gate at the head of a tail starts polling as soon as the side stream is free -- possibly long before its step starts on the
+    caller's stream.  Half a second of somebody else's work in front of the step must not trip it (its limit is 5 s; the main gate's 0.2 s
+    bounds a wait for a tail that is already running)"""
+    B = 8
+    m = _model(B)
+    z, xs, twh = _inputs(B, 2, 970)
+    m.template(z)
+    want = []
+    for x in xs:
+        o = m.track_step(x, twh, refine=True, stage=False)
+        torch.cuda.synchronize()
+        want.append({k: v.clone() for k, v in o.items() if v is not None})
+    m.set_pipeline(1)
+    for i, x in enumerate(xs):
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        torch.cuda._sleep(int(1.0e9))                       # ~0.4-0.6 s of device time on the step's own stream
+        t1.record()
+        o = m.track_step(x, twh, refine=True, stage=False)
+        m.pipeline_join()
+        torch.cuda.synchronize()
+        assert t0.elapsed_time(t1) > 250.0, t0.elapsed_time(t1)          # (longer than the main gate's limit: the test means something)
+        for k in want[i]:
+            assert torch.equal(o[k], want[i][k]), (i, k)
+    g, e = m.seq_status()
+    assert g > 0 and e == 0 and m.seq_recovered == 0
+
+
 def test_gate_timeout_is_loud_and_leaves_serial_steps_behind():
     """a gate that waits 0.2 s for its partner (a profiler that serialises the two queues produces exactly this) raises failure code 3: the
     next entry point returns SMK_E_SEQ, the context goes back to serial steps, and after template() the frames are right again -- here the
