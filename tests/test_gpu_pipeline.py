@@ -164,9 +164,10 @@ def test_a_slow_stream_in_front_of_the_step_is_not_a_gate_timeout():
         o = m.track_step(x, twh, refine=True, stage=False)
         m.pipeline_join()
         torch.cuda.synchronize()
-        assert t0.elapsed_time(t1) > 250.0, t0.elapsed_time(t1)          # (longer than the main gate's limit: the test means something)
         for k in want[i]:
             assert torch.equal(o[k], want[i][k]), (i, k)
+        if t0.elapsed_time(t1) < 250.0:                     # (shorter than the 0.2 s limit it is meant to exceed: correct, but it proved nothing)
+            pytest.skip("torch.cuda._sleep took only %.0f ms on this box" % t0.elapsed_time(t1))
     g, e = m.seq_status()
     assert g > 0 and e == 0 and m.seq_recovered == 0
 
