@@ -115,8 +115,11 @@ class Workload(object):
                 if getattr(e, "code", 0) != _lib.E_SEQ:
                     raise
                 self.fallbacks = getattr(self, "fallbacks", 0) + 1
-                self.pipeline = 0
                 torch.cuda.synchronize(self.device)
+                # the library leaves pipelining on for barrier / placement failures and turns it off for a gate time-out only:
+                # say explicitly what this loop runs from here on, so that join() / frame_latency() and the library agree
+                self.pipeline = 0
+                m.set_pipeline(0)
                 m.template(self.z)
                 o = m.track_step(x, self.twh, refine=self.refine, stage=False)
             self.last = (o["box"], o["loc"], o["mask"], o["refine"])
@@ -197,6 +200,9 @@ def body(w, res, i):
         res.box[r, :, :10 * 625].copy_(cls.reshape(w.B, -1))
         res.box[r, :, 10 * 625:].copy_(loc.reshape(w.B, -1))
     if ref is not None:
+        # pipelined steps write `refine` / `mask` on the library's side stream after step() returns: order the copy behind
+        # that tail (a no-op for serial steps), or it reads the previous frame's / half-written logits
+        w.join()
         res.masks[r].copy_(ref)
 
 

@@ -102,6 +102,9 @@ typedef struct smk_conv_geom {
 
 /* algo: low byte 0 = MFMA kernel, NHWC epilogue; 1 = naive kernel, NHWC epilogue;
  *                2 = MFMA kernel, NCHW-f32 epilogue; 3 = naive kernel, NCHW-f32 epilogue;
+ *                4 = conv3x3_halo_kernel (tile code 1 = 128 rows, else 64); 5 = conv_wreg_kernel (tile code 1..6 =
+ *                64x256 64x128 64x64 128x256 128x128 128x64; ring-depth bits 3 = four stages); 6 = conv_pp_kernel
+ *                (256 x 256 tiles, fp16 only, conv_pp.hip);
  *       second byte: bits 0-3 tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64, 5 256x128;
  *                    bits 4-5 K tile 0 auto, 1 = 128 B, 2 = 256 B; bits 6-7 LDS ring depth
  *                    0 auto, 1..3 = 2..4 stages.
@@ -156,7 +159,7 @@ int smk_host_conv2d_ex(const smk_conv_geom *g, const float *x, const float *w, c
                        const float *res, const int32_t *pos, float *y);
 
 /* Host only: which kernel the engine picks for ONE convolution of this geometry and batch (g->B streams) under the current
- * smk_tune knobs -- *kernel = 0 conv_igemm_kernel, 1 conv3x3_halo_kernel, 2 conv_wreg_kernel; *bm x *bn = workgroup shape;
+ * smk_tune knobs -- *kernel = 0 conv_igemm_kernel, 1 conv3x3_halo_kernel, 2 conv_wreg_kernel, 3 conv_pp_kernel; *bm x *bn = workgroup shape;
  * *seq_cfg = tile code inside a persistent per-XCD sequence (0 64x256, 1 64x128, 2 64x64, 3 128x256, 4 128x128) or -1 when
  * the layer cannot be part of one.  Lets the CPU test-suite pin the measured layer rules (profiles/r02_producer_waves_*). */
 int smk_host_plan_conv(const smk_conv_geom *g, int dtype, int with_res, int *kernel, int *bm, int *bn, int *seq_cfg);

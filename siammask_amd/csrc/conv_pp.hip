@@ -1,0 +1,381 @@
+// conv_pp.hip -- implicit-GEMM convolution on 256 x 256 tiles for the large-batch regime (BASELINE configs[4]: 64 search crops per
+// frame; experiments/siammask_sharp/resnet.py:64-76,195-206 -- the 3x3 shortcut / conv2 convolutions of layer2 / layer3 -- and
+// models/rpn.py:50-54 conv_search), f16 operands, fp32 accumulation, NHWC epilogue with bias (+ residual) (+ ReLU).
+//
+// Same contraction and the same k order per output as conv_wreg_kernel / conv_igemm_kernel (C[m][n] = sum_k A[m][k] * W[n][k], one
+// v_mfma_f32_32x32x16_f16 chain per accumulator in ascending k): the results are bit-identical to theirs.  What differs is the schedule.
+// conv_wreg_kernel keeps ONE MFMA-issuing wave per SIMD; whenever that wave waits (fragment reads, the K-tile barrier, weight
+// fragments from the L2) the matrix pipe idles, and at M = 61 504 rows nothing else hides it: 0.40-0.45 of the fp16 peak on the
+// long-K layers (profiles/r05_b64_kernel_table.json).  Here a workgroup is EIGHT waves in two groups of four (one wave of each group per
+// SIMD) that run the same program one barrier interval apart:
+//
+//        interval      2p          2p+1        2p+2        2p+3
+//        group 0    fetch(p)    multiply(p)  fetch(p+1)  multiply(p+1)
+//        group 1  multiply(p-1)  fetch(p)    multiply(p)  fetch(p+1)
+//
+// fetch(p)    = read this phase's operand fragments from LDS into registers, issue the LDS-DMA of one half tile (two 16-byte pieces per
+//               lane) for six phases later, counted vmcnt wait;
+// multiply(p) = eight MFMAs 32x32x16 (one 64 x 32 quadrant of the wave's 128 x 64 block over the K tile's 64 values) at raised priority.
+// So on every SIMD one wave feeds the matrix pipe while the other one fetches; the two meet at an s_barrier per interval.  A K tile
+// (64 values of K = 128 B per row) is four phases -- quadrants (m0,n0) (m0,n1) (m1,n1) (m1,n0) -- and four half tiles of 128 rows:
+// A0 / A1 = the m0 / m1 row halves of all waves, B0 / B1 = the n0 / n1 channel halves.  Each is read ONCE: B0 in the last phase of the
+// K tile before (its fragments stay in registers for phases 0 and 3), A0 in phase 0, B1 in phase 1, A1 in phase 2 -- 4 / 8 / 4 / 8
+// ds_read_b128 per wave and phase -- so every half-tile slot of the two-K-tile ring is free again at most three phases after its K tile
+// starts, which is what lets a 128 KB ring keep FOUR half tiles (64 KB per CU) in flight.
+// (profiles/r06b_pp_ablation.txt: with the stage issued BEFORE the reads and 12 / 4 / 8 / 0 reads per phase the fetch interval, not the
+//  multiply interval, set the pace -- 525 cycles per interval where the MFMAs alone take 268 and the fetches alone 322.)
+//
+// Hazards (one stage per phase, stage(h) issued in fetch(h - 6), half tile h = 4 t + x, x = 0 B0, 1 A0, 2 B1, 3 A1, read in phase
+// 4 t + {-1, 0, 1, 2}[x]):
+//   RAW  every wave waits s_waitcnt vmcnt(8) behind the stage of phase p (all its stages up to phase p - 4 have landed), then the
+//        barrier; fetch(p + 1) of either group comes after that barrier (group 0: next interval; group 1: two intervals later) and
+//        reads half tiles staged in phases <= p - 4.  The six phases of the tail issue no stage and wait vmcnt(0).
+//   WAR  the slot of half tile h held h - 8, last read in fetch(s - 3) (s = h - 6): retired two intervals before group 0's stage.
+// The fragment reads are inline-asm ds_read_b128: the compiler orders EVERY LDS access it knows about behind ALL outstanding LDS-DMA
+// (s_waitcnt vmcnt(0): it cannot tell the ring slots apart), which would drain the pipeline each phase; an asm read carries no memory
+// operand, so the counted waits above are the only ones, and a sched_barrier behind each lgkmcnt(0) keeps the MFMAs from being
+// hoisted over it.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "smk_kernels.h"
+
+namespace smk {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int PP_HALF = 128 * 128;              // one half tile: 128 rows x 128 B (64 halves of K)
+constexpr int PP_A = 0;                         // A region: [ring buffer 0 / 1][row half 0 / 1] half tiles
+constexpr int PP_B = 4 * PP_HALF;               // B region, same order; every read offset inside a region fits a 16-bit immediate
+constexpr int PP_LDE = 68;                      // epilogue staging pitch (floats)
+constexpr int PP_EPI = 64 * PP_LDE * 4;         // one wave's epilogue staging: 64 rows x 64 channels f32
+constexpr int PP_LDS = 8 * PP_EPI > 8 * PP_HALF ? 8 * PP_EPI : 8 * PP_HALF;
+static_assert(PP_LDS <= 160 * 1024, "LDS of a CU");
+
+template <int OFF> __device__ __forceinline__ void lds_read16(half8 &d, const unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && (OFF & 15) == 0, "ds_read_b128 immediate offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
+}  // namespace
+
+// ABL (measurement builds, `make MEASURE=1` / tools/measure/build_variant.sh with -DSMK_MEASURE; smk_tune "ablate"): parts of the K loop
+// removed -- 1 no LDS-DMA, 2 no fragment reads, 4 no MFMAs (results wrong by construction) -- or re-placed -- 8 no s_setprio,
+// 16 the fragment reads retired BEFORE the interval's first barrier, 32 the stage issued before the fragment reads (results right); 64 (with 2)
+// the operand registers hold pseudo-random fp16 values instead of zeros.
+// The product library carries ABL = 0 only.
+template <int ABL>
+__global__ __launch_bounds__(512, 1)
+void conv_pp_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[PP_LDS];
+    typedef _Float16 T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;         // group (row half of the tile) / channel quarter
+
+    // ---- tile: XCD-contiguous, tm-major (the tiles that share activation rows run on one XCD, next to each other) ----
+    const int tilesN = (p.Nst + 255) >> 8;
+    int t = (int)blockIdx.x;
+    if (p.xcd_mode != 0) {
+        const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int x = t & 7, j = t >> 3;
+        t = x * q + (x < r ? x : r) + j;
+    }
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // ---- staging side: per-lane rows.  Piece u (0 / 1) of half tile j lands in LDS row q = 64 u + (tid >> 3), 16-byte slot tid & 7;
+    //      LDS-DMA writes lane-linear, so the XOR swizzle of the fragment reads goes on the SOURCE chunk (same involution both sides).
+    const int srcchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    // A: LDS row q of half tile j = tile row 128 (q >> 6) + 64 j + (q & 63)   (the two groups' m_j halves side by side)
+    int a_base[2][2], a_ly0[2][2], a_lx0[2][2];
+    {
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + u * 128 + j * 64 + (tid >> 3);
+                const bool valid = m < p.M;
+                const int mm = valid ? m : 0;
+                const int b = mm / hw, rem = mm - b * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int ly0 = oy * p.stride - p.pad, lx0 = ox * p.stride_x - p.pad;
+                a_ly0[u][j] = valid ? ly0 : -0x4000;              // a row beyond M fails every bounds test: zeros
+                a_lx0[u][j] = lx0;
+                a_base[u][j] = (((b * p.Hs + ly0) * p.Ws + lx0) * p.Cs + p.cin_off) * (int)sizeof(T) + srcchunk * 16;
+            }
+    }
+    // B: LDS row q of half tile j = channel 64 (q >> 5) + 32 j + (q & 31); the (u, j) part of the row offset is wave-uniform
+    const int b_voff = ((n0 + (tid >> 8) * 64 + ((tid >> 3) & 31)) * p.Kpad + srcchunk * 8) * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, p.w_bytes, 0x00020000);
+    constexpr int OOB = 0x7ffff000;
+    auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const int g_cish = sgpr(p.ci_shift), g_Ci = sgpr(p.Ci), g_kwm = sgpr(p.kw_magic), g_kw = sgpr(p.kw), g_dil = sgpr(p.dil),
+              g_Hl = sgpr(p.Hl), g_Wl = sgpr(p.Wl), g_Ws = sgpr(p.Ws), g_Cs = sgpr(p.Cs), g_Kpad = sgpr(p.Kpad), g_kh = sgpr(p.kh);
+    unsigned char *const stage_base = smem + wave * 1024;
+
+    // half tile (K tile kt, kind X: 0 B0, 1 A0, 2 B1, 3 A1) -> ring buffer BUF
+    auto stage = [&](const int kt, auto bufc, auto xc) {
+        constexpr int BUF = decltype(bufc)::value, X = decltype(xc)::value;
+        constexpr int J = (X == 2 || X == 3) ? 1 : 0;
+        if constexpr (X == 1 || X == 3) {
+            const int k0 = kt << 6;
+            const int tap = k0 >> g_cish, c = k0 & (g_Ci - 1);
+            const int kh_i = (tap * g_kwm) >> 16, kw_i = tap - kh_i * g_kw;
+            const int dy = kh_i * g_dil, dx = kw_i * g_dil;
+            const int tapoff = ((dy * g_Ws + dx) * g_Cs + c) * (int)sizeof(T);
+            const bool tap_ok = kh_i < g_kh;             // (K tiles of the zero padding behind K: zeros, whatever the tensor holds)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool ok = tap_ok & ((unsigned)(a_ly0[u][J] + dy) < (unsigned)g_Hl) & ((unsigned)(a_lx0[u][J] + dx) < (unsigned)g_Wl);
+                const int off = ok ? a_base[u][J] + tapoff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_void_t *)(stage_base + PP_A + BUF * 2 * PP_HALF + J * PP_HALF + u * 8192),
+                                                         16, off, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int so = (kt << 7) + (u * 128 + J * 32) * g_Kpad * (int)sizeof(T);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t *)(stage_base + PP_B + BUF * 2 * PP_HALF + J * PP_HALF + u * 8192),
+                                                         16, b_voff, so, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment side: row frow of a 32-row block, 16-byte chunk (2 s + fhalf) of k-step s at slot chunk ^ ((row >> 1) & 7) ----
+    const int frow = lane & 31, fhalf = lane >> 5, fsw = (frow >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(lds_void_t *)smem;
+    unsigned va[4], vb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned ch = (unsigned)(((2 * s + fhalf) ^ fsw) << 4);
+        va[s] = lds0 + PP_A + (wr * 64 + frow) * 128 + ch;
+        vb[s] = lds0 + PP_B + (wc * 32 + frow) * 128 + ch;
+    }
+
+    floatx16 acc[2][2][2];                           // [row half jm][32-row block mb][channel half jn]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+    half8 fa[2][4], fb0[2][4], fb1[4];               // fb0: by ring buffer -- the next K tile's B0 fragments are read one phase early
+
+    const int nk = p.Kpad >> 6;                      // K tiles (Kpad is a multiple of 128 elements: nk is even)
+    const int H = nk << 2;                           // half tiles
+
+    // ---- prologue: six half tiles in flight (K tile 0 and B0, A0 of K tile 1), the first two landed, K tile 0's B0 fragments read ----
+    stage(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    stage(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    stage(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    stage(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+    stage(1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    stage(1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (!(ABL & 2)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) lds_read16<0>(fb0[0][s], vb[s]);
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one interval behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto mma = [&](half8 &a, half8 &b, floatx16 &c) {
+        if constexpr ((ABL & 4) != 0) asm volatile("" : "+v"(a), "+v"(b));     // (operands stay live, no matrix instruction)
+        else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    };
+    if constexpr ((ABL & 2) != 0) {
+        // (no fragment reads: the operand registers hold zeros -- or, with bit 64, pseudo-random fp16 values of magnitude 2^-3 .. 2^-2 with
+        //  random signs and mantissas: the matrix pipes' clock under load depends on the operand bits)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4v z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned hsh = ((unsigned)tid * 2654435761u + (unsigned)(s * 16 + q * 4 + d) * 40503u + 12345u) * 1664525u + 1013904223u;
+                    hsh ^= hsh >> 15;
+                    z[q][d] = (ABL & 64) ? ((hsh & 0x83ff83ffu) | 0x30003000u) : 0u;
+                }
+            asm volatile("" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+            fb1[s] = __builtin_bit_cast(half8, z[0]); fb0[0][s] = __builtin_bit_cast(half8, z[1]); fb0[1][s] = fb0[0][s];
+            fa[0][s] = __builtin_bit_cast(half8, z[2]); fa[1][s] = __builtin_bit_cast(half8, z[3]);
+        }
+    }
+    // one phase: PH8 = phase inside the 8-phase (two K tiles) body
+    auto phase = [&](const int pbase, auto ph8c) {
+        constexpr int PH8 = decltype(ph8c)::value;
+        constexpr int PH = PH8 & 3, BUF = PH8 >> 2;
+        constexpr int SX = (PH8 + 6) & 3, SBUF = ((PH8 + 6) >> 2) & 1;
+        // -- fetch interval: this phase's fragments first (their latency runs under the LDS-DMA issue), then one half tile for six
+        //    phases later, then the counted wait that covers what the NEXT phase reads --
+        const int h = pbase + PH8 + 6;
+        const bool more = h < H;
+        if constexpr ((ABL & 32) != 0) { if (more && !(ABL & 1)) stage(h >> 2, std::integral_constant<int, SBUF>{}, std::integral_constant<int, SX>{}); }
+        if constexpr ((ABL & 2) != 0) {
+            // (no fragment reads: the operands keep whatever the registers hold)
+        } else if constexpr (PH == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                lds_read16<BUF * 2 * PP_HALF>(fa[0][s], va[s]);
+                lds_read16<BUF * 2 * PP_HALF + 4096>(fa[1][s], va[s]);
+            }
+        } else if constexpr (PH == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) lds_read16<BUF * 2 * PP_HALF + PP_HALF>(fb1[s], vb[s]);
+        } else if constexpr (PH == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                lds_read16<BUF * 2 * PP_HALF + PP_HALF>(fa[0][s], va[s]);
+                lds_read16<BUF * 2 * PP_HALF + PP_HALF + 4096>(fa[1][s], va[s]);
+            }
+        } else {
+            // the next K tile's B0 (other ring buffer; behind the last K tile: a read of stale bytes that nothing uses)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) lds_read16<(BUF ^ 1) * 2 * PP_HALF>(fb0[BUF ^ 1][s], vb[s]);
+        }
+        if constexpr ((ABL & 32) == 0) { if (more && !(ABL & 1)) stage(h >> 2, std::integral_constant<int, SBUF>{}, std::integral_constant<int, SX>{}); }
+        if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((ABL & 16) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // -- multiply interval --
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                if constexpr (PH == 0) mma(fa[mb][s], fb0[BUF][s], acc[0][mb][0]);
+                if constexpr (PH == 1) mma(fa[mb][s], fb1[s], acc[0][mb][1]);
+                if constexpr (PH == 2) mma(fa[mb][s], fb1[s], acc[1][mb][1]);
+                if constexpr (PH == 3) mma(fa[mb][s], fb0[BUF][s], acc[1][mb][0]);
+            }
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int pbase = 0; pbase < H; pbase += 8) {
+        phase(pbase, std::integral_constant<int, 0>{});
+        phase(pbase, std::integral_constant<int, 1>{});
+        phase(pbase, std::integral_constant<int, 2>{});
+        phase(pbase, std::integral_constant<int, 3>{});
+        phase(pbase, std::integral_constant<int, 4>{});
+        phase(pbase, std::integral_constant<int, 5>{});
+        phase(pbase, std::integral_constant<int, 6>{});
+        phase(pbase, std::integral_constant<int, 7>{});
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // group 0 meets group 1's last interval
+    __syncthreads();                                 // every fragment read has retired: the LDS is free
+
+    // ---- epilogue, per wave: accumulators -> LDS (64 rows x 64 channels f32 at a time) -> bias / residual / ReLU -> NHWC f16 in
+    //      full 128-byte lines.  Same arithmetic as wreg_tile's epilogue.
+    float *const e = (float *)(smem + wave * PP_EPI);
+    const int erow = lane >> 3, c8 = (lane & 7) * 8;
+    const int n = n0 + wc * 64 + c8;
+    const bool ncol_ok = n < p.Nst;
+    float bv[8];
+    if (ncol_ok) {
+        const floatx4 b0 = *(const floatx4 *)(p.bias + n), b1 = *(const floatx4 *)(p.bias + n + 4);
+        bv[0] = b0[0]; bv[1] = b0[1]; bv[2] = b0[2]; bv[3] = b0[3];
+        bv[4] = b1[0]; bv[5] = b1[1]; bv[6] = b1[2]; bv[7] = b1[3];
+    }
+    T *const out = (T *)p.out;
+#pragma unroll
+    for (int jm = 0; jm < 2; ++jm) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    e[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * PP_LDE + jn * 32 + frow] = acc[jm][mb][jn][r];
+        const int mrow0 = m0 + wr * 128 + jm * 64;
+        half8 rv[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rv[ps][u] = (_Float16)0.f;
+        if (p.res_mode != RES_NONE && ncol_ok) {
+            const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc((void *)p.res, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int m = mrow0 + ps * 8 + erow;
+                if (m < p.M) {
+                    const int ro = (int)(((size_t)m * p.res_Cs + p.res_coff + n) * sizeof(T));
+                    rv[ps] = __builtin_bit_cast(half8, p.res_nt ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 2)
+                                                                : __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro, 0, 0));
+                }
+            }
+        }
+        if (ncol_ok) {
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = ps * 8 + erow, m = mrow0 + row;
+                if (m < p.M) {
+                    const float *er = e + row * PP_LDE + c8;
+                    const floatx4 x0 = *(const floatx4 *)er, x1 = *(const floatx4 *)(er + 4);
+                    half8 o;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float v = (u < 4 ? x0[u & 3] : x1[u & 3]) + bv[u];
+                        if (p.res_mode == RES_PRE_RELU) v += (float)rv[ps][u];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.res_mode == RES_POST_RELU) v += (float)rv[ps][u];
+                        o[u] = (_Float16)v;
+                    }
+                    *(half8 *)(out + (size_t)m * p.Cos + p.cout_off + n) = o;
+                }
+            }
+        }
+    }
+}
+
+// f16, NHWC epilogue, one group, plain [Npad][Kpad] pack, channels a power of two >= one K tile (a K tile never straddles a tap), the
+// whole input tensor as the logical image (no window / upsampling / per-stream origin), 32-bit buffer offsets
+bool conv_pp_eligible(const ConvParams &p, int dtype) {
+    return dtype == DT_F16 && p.out_mode == OUT_NHWC && p.wgt != nullptr && p.buf_lds && (p.Kpad % 128) == 0 && p.groups <= 1 &&
+           p.ci_shift >= 6 && !p.ups && !p.pos && p.org_y == 0 && p.org_x == 0 && p.Hl == p.Hs && p.Wl == p.Ws &&
+           p.in_bytes < 0x7fff0000u && p.w_bytes < 0x7fff0000u && (p.Nst % 8) == 0;
+}
+
+int launch_conv_pp(const ConvParams &p, void *stream) {
+    if (!conv_pp_eligible(p, DT_F16)) return 1;
+    const int tiles = ((p.M + 255) / 256) * ((p.Nst + 255) / 256);
+#ifdef SMK_MEASURE
+    switch (g_tune.ablate) {
+    case 1: hipLaunchKernelGGL(conv_pp_kernel<1>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 2: hipLaunchKernelGGL(conv_pp_kernel<2>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 3: hipLaunchKernelGGL(conv_pp_kernel<3>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 4: hipLaunchKernelGGL(conv_pp_kernel<4>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 5: hipLaunchKernelGGL(conv_pp_kernel<5>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 6: hipLaunchKernelGGL(conv_pp_kernel<6>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 7: hipLaunchKernelGGL(conv_pp_kernel<7>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 8: hipLaunchKernelGGL(conv_pp_kernel<8>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 16: hipLaunchKernelGGL(conv_pp_kernel<16>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 32: hipLaunchKernelGGL(conv_pp_kernel<32>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 67: hipLaunchKernelGGL(conv_pp_kernel<67>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 66: hipLaunchKernelGGL(conv_pp_kernel<66>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    case 24: hipLaunchKernelGGL(conv_pp_kernel<24>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p); return hipGetLastError() == hipSuccess ? 0 : -4;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(conv_pp_kernel<0>, dim3(tiles), dim3(512), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk

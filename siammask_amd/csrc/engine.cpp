@@ -1207,6 +1207,18 @@ static bool seq_wanted(const smk_ctx *c, int B) {
 
 // conv_wreg_kernel (weights global -> VGPR) or the LDS-staged kernels?  Returns the tile code 1..6
 // (64x256, 64x128, 64x64, 128x256, 128x128, 128x64) or 0.
+// CUs of the current device; host-only callers (smk_host_plan_conv on a box without a GPU) plan for the MI355X's 256
+static long device_cus() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 256; }
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 static const int WREG_TILE[8][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}, {96, 256}};
 static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (o.algo_naive || !conv_wreg_eligible(p, dtype)) return 0;
@@ -1241,7 +1253,7 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
                 // 128 x 256 with 129 .. 255 workgroups leaves CUs idle for a whole tile time (conv_search at B = 8: 53 x 3 = 159
                 // tiles on 256 CUs); 96 rows (code 7) = 213 tiles, still one round, each 3/4 as long (smk_tune "wreg96", round 5)
                 if (cand[ci] == 4 && g_tune.wreg96) {
-                    const long ncu = 256, tn = (p.Nst + 255) / 256 * ng;
+                    const long ncu = device_cus(), tn = (p.Nst + 255) / 256 * ng;
                     const long t128 = (long)((p.M + 127) / 128) * tn, t96 = (long)((p.M + 95) / 96) * tn;
                     if (((t128 + ncu - 1) / ncu) * 128 > ((t96 + ncu - 1) / ncu) * 96 && t96 <= 4 * ncu) return 7;
                 }
@@ -1259,6 +1271,20 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     return 0;
 }
 static int wreg_stages() { return g_tune.wreg_stages ? g_tune.wreg_stages : 3; }
+
+// conv_pp_kernel (conv_pp.hip: 256 x 256 tiles, two wave groups alternating between fetching and multiplying) takes the long-K
+// convolutions once 256-row tiles fill the chip in (nearly) whole rounds -- the 3x3 shortcuts and layer3's conv2 from B ~ 53 (BASELINE
+// configs[4]): +1.3..3.8 % per launch over the register-fed 128 x 256 tile; conv_search's 633 tiles are 2.47 rounds (0.82 of three) and
+// stay on the register-fed kernel (-6 %); profiles/r06a_pp_first_contact.txt.  Below ~200 tiles the launch is a partial round of a few
+// long tiles and the smaller tiles win (B = 32: -6..-60 %).  pp = 2 (A/B knob): any K, e.g. the Bottlenecks' 1x1 convolutions.
+static bool pp_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
+    if (!g_tune.pp || o.algo_naive || o.halo || o.wreg || o.tile_code || !conv_pp_eligible(p, dtype)) return false;
+    const long K = (long)p.kh * p.kw * p.Ci;
+    const long tiles = (long)((p.M + 255) / 256) * ((p.Nst + 255) / 256), ncu = device_cus();
+    const long rounds = (tiles + ncu - 1) / ncu;
+    if (tiles < 200 || tiles * 10 < rounds * ncu * 9 || p.Nst < 256 || (p.Nst % 256) != 0) return false;
+    return g_tune.pp == 2 || K >= 2304;
+}
 
 static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, int B, const ConvOpt &o,
                     hipStream_t s) {
@@ -1295,7 +1321,13 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     if (bm && !o.halo && conv_ksplit(p, c->dtype, t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
     // (policy 1 decides between the register-fed and the patch-sharing kernel itself; the round-2 table only covered the
     //  layers the patch-sharing kernel does not take)
-    const int wr = (o.halo || (bm && !o.wreg && g_tune.wreg < 2 && g_tune.wreg_policy == 0)) ? 0 : wreg_choice(p, o, c->dtype);
+    if (pp_choice(p, o, c->dtype)) {
+        ProfScope ps(c, s, id, "conv_pp<f16,256x256>", flop, bytes);
+        rc = launch_conv_pp(p, s);
+        if (rc == 1) ps.cancel();
+        else bm = 0;
+    }
+    const int wr = (rc != 1 || o.halo || (bm && !o.wreg && g_tune.wreg < 2 && g_tune.wreg_policy == 0)) ? 0 : wreg_choice(p, o, c->dtype);
     if (wr) {
         // weights straight into registers, activations through LDS
         ConvBatch cb;
@@ -2426,6 +2458,8 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "pipe_eager")) g_tune.pipe_eager = value & 3;
     else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "front_occ1")) g_tune.front_occ1 = value & 3;
+    else if (!strcmp(key, "pp")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pp 0..2"); g_tune.pp = value; }
     else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
     else if (!strcmp(key, "pipe_two_form")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_two_form 0..2"); g_tune.pipe_two_form = value; }
     else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
@@ -2456,7 +2490,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2811,8 +2845,10 @@ int smk_step(smk_ctx *c, const float *x, int B, int flags, const double *target_
     CHK(seq_health(c));
     hipStream_t s = (hipStream_t)stream;
     // pipelined: only a step with a Refine tail has something to overlap; the profiler times launches one by one; the fork / join
-    // concurrency knob and a persistent sequence that includes layer1 (measurement knobs) keep the serial step
-    if (c->pipe_depth > 0 && refine_out && !c->prof && !parallel_ok(c) && g_tune.seq_first_stage >= 1 && !g_tune.mask_overlap) {
+    // concurrency knob and a persistent sequence that includes layer1 (measurement knobs) keep the serial step; so does split-K
+    // (ONE scratch + arrival-counter set per context: layer1 of frame f + 1 and the Refine convolutions of frame f would share it)
+    if (c->pipe_depth > 0 && refine_out && !c->prof && !parallel_ok(c) && g_tune.seq_first_stage >= 1 && !g_tune.mask_overlap &&
+        !g_tune.ksplit) {
         int rc = step_pipelined(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, s);
         if (rc) return rc;
         c->track_B = B;
@@ -3080,6 +3116,9 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         cb.p[0] = p;
         rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], ((o.tile_code >> 6) & 3) == 3 ? 4 : 3, s);
         if (rc == 1) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry / dtype is not eligible for conv_wreg_kernel");
+    } else if (mode == 6) {                            // conv_pp_kernel (256 x 256 tiles)
+        rc = dtype == DT_F16 ? launch_conv_pp(p, s) : 1;
+        if (rc == 1) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry / dtype is not eligible for conv_pp_kernel");
     } else if (o.halo) {
         ConvParams ph = p;
         ph.wgt = pc.w_halo;
@@ -3380,13 +3419,19 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
     CHK(fill_geom(g, pc, in, o, Ho, Wo));
     const size_t es = esize(dtype);
     TmpBufs tmp;
+    // SMK_BENCH_FILL (measurement aid): what the ACTIVATIONS hold -- uniform [-1, 1) (default), "zero", "relu" (negative values -> 0).  The
+    // matrix pipes' clock under load depends on the operand bits (MI355X_MICROARCH.md: zero-filled operands +15..21 % TF/s).
+    const char *fm = getenv("SMK_BENCH_FILL");
+    const int fill_mode = !fm ? 0 : (!strcmp(fm, "zero") ? 1 : (!strcmp(fm, "relu") ? 2 : 0));
     auto fill = [&](void **dst, size_t elems, float scale, unsigned seed) -> int {
         CHK(tmp.alloc(dst, elems * es));
         std::vector<unsigned char> h(elems * es);
         unsigned st = seed * 2654435761u + 12345u;
         for (size_t i = 0; i < elems; ++i) {
             st = st * 1664525u + 1013904223u;
-            const float v = ((int)((st >> 9) & 0xffff) - 32768) * (scale / 32768.f);
+            float v = ((int)((st >> 9) & 0xffff) - 32768) * (scale / 32768.f);
+            if (seed == 1 && fill_mode == 1) v = 0.f;                       // SMK_BENCH_FILL=zero: activations all zero
+            if (seed == 1 && fill_mode == 2) v = v > 0.f ? v : 0.f;         // SMK_BENCH_FILL=relu: half of them zero, like a ReLU output
             if (dtype == DT_F16) ((_Float16 *)h.data())[i] = (_Float16)v; else ((float *)h.data())[i] = v;
         }
         HIPCHK(hipMemcpy(*dst, h.data(), elems * es, hipMemcpyHostToDevice));
@@ -3434,7 +3479,9 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
         if (!conv_wreg_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_wreg_kernel");
     }
     const int wr_stages = ((o.tile_code >> 6) & 3) == 3 ? 4 : 3;
+    if (mode == 6 && !conv_pp_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_pp_kernel");
     auto launch = [&]() {
+        if (mode == 6) return launch_conv_pp(p, s);
         if (wr) {
             ConvBatch cb;
             cb.n = 1;
@@ -3538,7 +3585,8 @@ int smk_host_plan_conv(const smk_conv_geom *g, int dtype, int with_res, int *ker
     int hb = halo_choice(pc, p, o, dtype);
     if (hb && conv_ksplit(p, dtype, t) > 1) hb = 0;
     const int wr = (hb && g_tune.wreg < 2 && g_tune.wreg_policy == 0) ? 0 : wreg_choice(p, o, dtype);
-    if (wr) { *kernel = 2; *bm = WREG_TILE[wr][0]; *bn = WREG_TILE[wr][1]; }
+    if (pp_choice(p, o, dtype)) { *kernel = 3; *bm = 256; *bn = 256; }
+    else if (wr) { *kernel = 2; *bm = WREG_TILE[wr][0]; *bn = WREG_TILE[wr][1]; }
     else if (hb) { *kernel = 1; *bm = hb; *bn = 128; }
     else { *kernel = 0; *bm = t.bm; *bn = t.bn; }
     SeqLayer L;

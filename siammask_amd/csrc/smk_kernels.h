@@ -215,6 +215,10 @@ struct Tuning {
                                // waves), 1 = the rule fitted with four (wreg_choice)
     int npw = 4;               // conv_wreg / conv_seq: producer waves per workgroup (2 or 4; measured: profiles/r02_producer_waves_2_vs_4.txt)
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
+    int pp = 1;                // fp16 NHWC convolutions with M >= 32768 rows, K >= 2304 and >= 200 tiles of 256 x 256 through conv_pp_kernel (0 off, 1 the
+                               // rule in engine.cpp pp_choice, 2 wherever eligible)
+    int front_occ1 = 0;        // A/B knob: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
+                               // step's tail run BESIDE the next frame's front end then, instead of taking turns with it?
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
@@ -388,6 +392,10 @@ int launch_conv_halo(const ConvParams &p, int dtype, int bm, void *stream);
 // {64,128,256}; returns 1 when a problem of the batch is not eligible
 bool conv_wreg_eligible(const ConvParams &p, int dtype);
 int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stream);
+// 256 x 256 tiles, eight waves in two alternating groups, both operands through LDS (conv_pp.hip): the long-K convolutions of
+// the large-batch regime; returns 1 when the problem is not eligible
+bool conv_pp_eligible(const ConvParams &p, int dtype);
+int launch_conv_pp(const ConvParams &p, void *stream);
 // a sequence of convolutions as one persistent launch of `grid` workgroups (one per CU, a multiple of 8)
 int launch_conv_seq(const SeqArgs &a, int grid, void *stream);
 // ONE fused (conv3 + residual + ReLU, next 1x1) pair as its own launch over M = B * H * W rows (code: SEQ_CFG_C3C1_L3 / _L2)

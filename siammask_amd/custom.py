@@ -260,7 +260,10 @@ class Custom(nn.Module):
         return x.to(torch.float32).contiguous()
 
     def _out(self, key, shape, device, dtype=torch.float32):
-        if self._graph:
+        # pipelined steps: the library's private side stream writes `refine` / `mask` after track_step returns, and torch's caching
+        # allocator does not know that stream -- a fresh tensor dropped by the caller before pipeline_join() could be handed out
+        # again while the tail still writes into it.  Persistent buffers (as in graph mode) cannot be recycled under the tail.
+        if self._graph or getattr(self, "_pipeline", 0):
             return self._buf(key, shape, device, dtype)
         return torch.empty(shape, dtype=dtype, device=device)
 

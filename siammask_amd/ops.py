@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4, "wreg": 5}
+ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4, "wreg": 5, "pp": 6}
 WREG_TILE = {(64, 256): 1, (64, 128): 2, (64, 64): 3, (128, 256): 4, (128, 128): 5, (128, 64): 6}
 TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5}
 
@@ -155,7 +155,7 @@ def maxpool3x3s2(x, dtype="f32"):
 
 
 def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=None, kt=0, stages=0,
-               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50, halo=False, wreg=False):
+               res=False, nchw=False, win=None, pos_mul=0, pos_add=0, iters=50, halo=False, wreg=False, pp=False):
     """average microseconds per launch of the MFMA conv kernel on this geometry (smk_bench_conv)"""
     g = _lib.ConvGeom()
     g.B, g.Cin, g.H, g.W = B, Cin, H, W
@@ -165,7 +165,9 @@ def bench_conv(B, Cin, H, W, Cout, k, stride=1, pad=0, dil=1, dtype="f16", tile=
     if win is not None:
         g.win, g.Hl, g.Wl = 1, win[0], win[1]
     us = ctypes.c_float(0.0)
-    if wreg:
+    if pp:
+        code = 6
+    elif wreg:
         code = 5 | (wreg_code(tile, stages) << 8)
     else:
         code = (4 if halo else (2 if nchw else 0)) | (tile_code(tile, kt, stages) << 8)

@@ -361,3 +361,41 @@ def test_conv_wreg_producer_variants_bit_equal():
                 assert torch.equal(ys[0], y), (tile, v)
     finally:
         _lib.tune(**saved)
+
+
+PP_CASES = [
+    # cin, cout, k, stride, pad, dil, hw, B, with_res      (M spans several 256-row tiles, the last one ragged)
+    (256, 256, 3, 1, 2, 2, 31, 2, False),    # layer3 conv2: dilation 2 (resnet.py:69-72,165), 8 tiles, tail of 130 rows
+    (256, 512, 3, 2, 0, 1, 63, 1, False),    # layer2.0 shortcut: 3x3 stride 2 pad 0 (resnet.py:195-206), two channel tiles
+    (256, 768, 3, 1, 0, 1, 31, 1, False),    # conv_search x3 as one N = 768 GEMM (models/rpn.py:50-54), 29 x 29 outputs
+    (512, 1024, 3, 1, 1, 1, 15, 2, False),   # layer3.0 shortcut: K = 4608 (72 K tiles), four channel tiles
+    (64, 248, 3, 1, 1, 1, 25, 1, True),      # K = 576 -> 640 (a K tile of pure padding), N overhang, residual + ReLU
+    (1024, 256, 1, 1, 0, 1, 20, 1, True),    # 1x1, long K, residual
+    (128, 256, 1, 1, 0, 1, 9, 3, False),     # two K tiles only (the ring's prologue covers the whole K), M = 243 < one tile
+]
+
+
+@pytest.mark.parametrize("cfg", PP_CASES)
+def test_conv_pp_kernel(cfg):
+    """conv_pp_kernel (256 x 256 tiles, two wave groups alternating between LDS-DMA / fragment reads and MFMAs, both operands
+    through LDS; the long-K convolutions of the B = 64 regime) against the oracle, and BIT-equal to conv_wreg_kernel's 128 x 256
+    tile: same MFMA shape, same k order per accumulator, same epilogue arithmetic.  Run three times: a ring hazard would show
+    as a rare wrong tile, not as a wrong kernel."""
+    ops = _ops()
+    cin, cout, k, stride, pad, dil, hw, B, with_res = cfg
+    rng = np.random.default_rng(hash(cfg) & 0xffff)
+    x, w, b = _rand(rng, B, cin, hw, hw), _rand(rng, cout, cin, k, k) / np.sqrt(cin * k * k), _rand(rng, cout)
+    ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ref = O.conv2d(_q(x, "f16"), _q(w, "f16"), b.astype(np.float64), stride, pad, dil)
+    rd = None
+    if with_res:
+        res = _rand(rng, B, cout, ho, ho)
+        ref = ref + _q(res, "f16")
+        rd = torch.from_numpy(res).cuda()
+    ref = np.maximum(ref, 0)
+    xd = torch.from_numpy(x).cuda()
+    yw = ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16", algo="wreg", tile=(128, 256), stages=3)
+    for rep in range(3):
+        y = ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16", algo="pp")
+        assert rel_err(y.cpu().numpy(), ref) <= TOL["f16"], (cfg, rep, rel_err(y.cpu().numpy(), ref))
+        assert torch.equal(y, yw), (cfg, rep, float((y - yw).abs().max()))

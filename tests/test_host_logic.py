@@ -203,7 +203,7 @@ def _plan(B, cin, hw, cout, k, stride=1, pad=0, dil=1, res=False, win=None, dtyp
     out = [ctypes.c_int(0) for _ in range(4)]
     _lib.check(_lib.lib().smk_host_plan_conv(ctypes.byref(g), _lib.DTYPE[dtype], int(res), *[ctypes.byref(o) for o in out]))
     kernel, bm, bn, cfg = [o.value for o in out]
-    return ("igemm", "halo", "wreg")[kernel], (bm, bn), cfg
+    return ("igemm", "halo", "wreg", "pp")[kernel], (bm, bn), cfg
 
 
 def test_layer_rules_are_the_measured_ones():
@@ -237,9 +237,13 @@ def test_layer_rules_are_the_measured_ones():
     assert _plan(1, 128, 31, 128, 3, pad=1)[0] == "halo"                       # l2.c2 (K = 1152)
     # B = 64: wide / long-K layers on 128x256 register-fed tiles, narrow short-K ones on LDS-staged 128-row tiles
     assert _plan(64, 1024, 31, 256, 1)[:2] == ("wreg", (128, 256))             # l3.c1
-    assert _plan(64, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (128, 256))  # l3.c2
+    # ... and from round 6 the long-K 3x3 layers whose 256 x 256 tiles fill whole rounds on conv_pp_kernel (profiles/r06a_pp_first_contact.txt)
+    assert _plan(64, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("pp", (256, 256))  # l3.c2: 241 tiles = 0.94 of one round
+    assert _plan(64, 512, 31, 1024, 3, pad=1)[:2] == ("pp", (256, 256))        # l3.0.ds: 964 tiles = 0.94 of four rounds
+    assert _plan(64, 256, 63, 512, 3, stride=2)[:2] == ("pp", (256, 256))      # l2.0.ds
+    assert _plan(32, 256, 31, 256, 3, pad=2, dil=2)[0] != "pp"                 # B = 32: 121 tiles, a partial round of long tiles
     assert _plan(64, 256, 31, 1024, 1, res=True)[:2] == ("wreg", (128, 256))   # l3.c3
-    assert _plan(64, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))              # conv_search
+    assert _plan(64, 256, 31, 768, 3)[:2] == ("wreg", (128, 256))              # conv_search: 633 tiles of 256 x 256 = 2.47 rounds (0.82 of three): stays
     assert _plan(64, 512, 31, 128, 1)[0] == "igemm"                            # l2.c1
     assert _plan(64, 256, 63, 64, 1)[0] == "igemm"                             # l1.c1
     assert _plan(64, 128, 31, 128, 3, pad=1)[0] == "halo"                      # l2.c2

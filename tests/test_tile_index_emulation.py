@@ -11,7 +11,7 @@ import pytest
 EMU = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "measure", "emu")
 
 
-@pytest.mark.parametrize("script", ["emu_c3c1_tile.py", "emu_wreg_halo_tile.py", "emu_c3c1p_tile.py", "emu_c3c1s_tile.py", "emu_c2front_tile.py"])
+@pytest.mark.parametrize("script", ["emu_c3c1_tile.py", "emu_wreg_halo_tile.py", "emu_c3c1p_tile.py", "emu_c3c1s_tile.py", "emu_c2front_tile.py", "emu_conv_pp.py"])
 def test_tile_index_arithmetic(script, capsys):
     runpy.run_path(os.path.join(EMU, script), run_name="__main__")      # the scripts assert; their table goes to stdout
     out = capsys.readouterr().out
