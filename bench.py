@@ -202,7 +202,8 @@ def body(w, res, i):
     if ref is not None:
         # pipelined steps write `refine` / `mask` on the library's side stream after step() returns: order the copy behind
         # that tail (a no-op for serial steps), or it reads the previous frame's / half-written logits
-        w.join()
+        if hasattr(w, "join"):
+            w.join()
         res.masks[r].copy_(ref)
 
 

@@ -108,7 +108,11 @@ struct TeamWait {
 // carrying it costs every other routine of the kernel (196 against 100 spilled SGPRs: +7 us on the B = 8 sequence, profiles/r04x_*)
 template <int NPW, int CLK = 0, int T3 = 0>
 __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqArgs a) {
-    constexpr int SEQ_LDS = (!T3 || WregLds<4, 3>::v > C3C1Lds<256, 1024, 256>::vx) ? WregLds<4, 3>::v : C3C1Lds<256, 1024, 256>::vx;
+    // (resident trunk: the patch-sharing 3x3 tile between two pairs works behind the pair's Y image -- two patch buffers, which also
+    //  hold its 64-row accumulator hand-over)
+    constexpr int SEQ_LDS0 = (!T3 || WregLds<4, 3>::v > C3C1Lds<256, 1024, 256>::vx) ? WregLds<4, 3>::v : C3C1Lds<256, 1024, 256>::vx;
+    constexpr int SEQ_LDS = SEQ_LDS0 > SEQ_YRES_BYTES + 2 * HALO_PB ? SEQ_LDS0 : SEQ_YRES_BYTES + 2 * HALO_PB;
+    static_assert(4 * 64 * 68 * 4 <= 2 * HALO_PB && C3C1Lds<256, 1024, 256>::A_OFF == SEQ_YRES_BYTES && C3C1Lds<128, 512, 128>::A_OFF <= SEQ_YRES_BYTES, "resident Y");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SEQ_LDS];
     static_assert(C3C1Lds<256, 1024, 256>::v <= WregLds<4, 3>::v && C3C1Lds<128, 512, 128>::vx <= SEQ_LDS && SEQ_LDS + 64 <= 160 * 1024, "LDS of the fused tiles");
     static_assert(NPW == 4, "c3c1_tile computes on all eight waves");
@@ -215,8 +219,10 @@ __global__ __launch_bounds__((4 + NPW) * 64, 1) void conv_seq_kernel(const SeqAr
                 }
                 else if (halo) {
                     const int ty = t / halo_tn, hn0 = (t - ty * halo_tn) * 64;
-                    if (cfg == SEQ_CFG_HALO128) alive = wreg_halo_tile<4, NPW, HALO_D128, HALO_SB128, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
-                    else alive = wreg_halo_tile<2, NPW, HALO_D64, 0, CLK>(L, img, ty, hn0, smem, tclk, slot, nslots, w);
+                    const bool hi = (L.a_stage & SEQ_LDS_HI) != 0;           // a pair's Y image stays in the first 64 KB
+                    unsigned char *hsm = smem + (hi ? SEQ_YRES_BYTES : 0);
+                    if (cfg == SEQ_CFG_HALO128) alive = wreg_halo_tile<4, NPW, HALO_D128, HALO_SB128, CLK>(L, img, ty, hn0, hsm, tclk, slot, nslots, w, hi);
+                    else alive = wreg_halo_tile<2, NPW, HALO_D64, 0, CLK>(L, img, ty, hn0, hsm, tclk, slot, nslots, w, hi);
                 }
                 else if (cfg == 0) alive = wreg_tile<2, 4, 1, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 256, smem, tclk, kt0, w);
                 else if (cfg == 1) alive = wreg_tile<2, 2, 2, 3, 16, 2, NPW, CLK>(L, 0, m0, m_end, tn * 128, smem, tclk, kt0, w);

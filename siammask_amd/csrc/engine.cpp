@@ -113,6 +113,18 @@ constexpr size_t KS_PART_FLOATS = 8u << 20;      // 32 MB: e.g. 256 tiles x 4 pa
 constexpr int KS_CNT = 8192;
 constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 8 + 8 * 4 + 4;     // decode_kernel's cross-workgroup scratch
 
+// The forms of the pipelined step that measured slower than the default (a cross-queue event join, hipStreamWaitValue32, eager launches,
+// the two other depth-2 forms; profiles/r05a/e/f/j/o_*) are A/B arms of measurement builds only: in the product library the four knobs are
+// compile-time constants, so the arms are not even compiled.
+#ifdef SMK_MEASURE
+#define PIPE_JOIN (g_tune.pipe_join)
+#define PIPE_SIG (g_tune.pipe_sig)
+#define PIPE_EAGER (g_tune.pipe_eager)
+#define PIPE_TWO_FORM (g_tune.pipe_two_form)
+#else
+constexpr int PIPE_JOIN = 1, PIPE_SIG = 2, PIPE_EAGER = 0, PIPE_TWO_FORM = 1;
+#endif
+
 static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
 
 // host-side packing of ONE weight tensor [Cout][Cin][k][k] (already scaled) into rows of a
@@ -950,6 +962,42 @@ static void seq_fuse_pairs(SeqLayer *L, int n, int B, const std::vector<char> *l
     }
 }
 
+// Resident trunk (round 6; smk_kernels.h SEQ_YRES_*): consecutive fused pairs of one ResNet layer -- [conv3 k + conv1 k+1], conv2 k+1 on a
+// patch-sharing tile, [conv3 k+1 + conv1 k+2] -- run on the same 32-row tiles; with ONE image per team and a tile per workgroup the
+// same workgroup owns the same rows in both, and the second pair's residual is the Y image the first one left in its LDS
+// (experiments/siammask_sharp/resnet.py:80-103: `out += residual`, residual = the previous block's output).  Marks: the second
+// pair does not fetch its residual rows (64 KB per CU "usually from beyond the L2", profiles/r05_seq_phase_clocks.txt: 3.0-3.5 of a
+// layer3 pair's 17-18 us), the first one does not store Y when nobody else reads the tensor, the 3x3 convolution between them works
+// in the LDS behind the image.  Values and summation orders are unchanged: bit-identical (tests/test_gpu_seq.py).
+// `keep` (per-op tests): records whose output the caller reads back.
+static int g_seq_yres_last = 0;           // pairs that found their residual resident in the list launched last (smk_tune_get "seq_yres_last")
+static void seq_mark_resident(SeqLayer *L, int n, int B, int nslots, const void *extern_read = nullptr, const std::vector<char> *keep = nullptr) {
+    g_seq_yres_last = 0;
+    if (!g_tune.seq_yres || B > 8) return;               // (image b runs on team b % 8: from nine images on a workgroup owns two tiles per pair)
+    int prev = -1;
+    for (int i = 0; i + 1 < n; ++i) {
+        const int cfg = L[i].cfg;
+        if (cfg != SEQ_CFG_C3C1_L3 && cfg != SEQ_CFG_C3C1_L2) continue;
+        const int p = prev;
+        prev = i;
+        if (p < 0 || L[p].cfg != cfg || i != p + 3) continue;
+        const int mid = L[p + 2].cfg;
+        if (mid != SEQ_CFG_HALO64 && mid != SEQ_CFG_HALO128) continue;
+        if ((L[i].Ho * L[i].Wo + 31) / 32 > nslots || L[i].Ho != L[p].Ho || L[i].Wo != L[p].Wo) continue;
+        if (L[i].res != L[p].out || L[i].res_Cs != L[p].Cos || L[i].res_coff != L[p].cout_off) continue;
+        L[i].a_stage |= SEQ_YRES_IN;
+        L[p + 2].a_stage |= SEQ_LDS_HI;
+        ++g_seq_yres_last;
+        // the store of Y: only the pair's own second record (from LDS) and this residual read the tensor?
+        bool others = L[p].out == extern_read || (keep && (*keep)[p]);
+        for (int j = 0; j < n && !others; ++j) {
+            if (j != p + 1 && L[j].in == L[p].out) others = true;
+            if (j != i && L[j].res == L[p].out) others = true;
+        }
+        if (!others) L[p].a_stage |= SEQ_YRES_NOSTORE;
+    }
+}
+
 // Triples (round 4): [conv2 (3x3, stride 1, pad = dilation), conv3, the next 1x1] of a Bottleneck as ONE tile routine on image-row
 // tiles (c3c1_tile.inc, FRONT = 1).  Runs behind seq_fuse_pairs: a marked pair (i + 1, i + 2) whose first record reads what record i --
 // the block's 3x3 convolution -- writes, and nobody else reads it.  The barrier between conv2 and the pair disappears with the
@@ -1092,6 +1140,7 @@ static int seq_flush(smk_ctx *c, int B, hipStream_t s) {
         for (int i = 0; i < a.n; ++i) a.L[i] = c->seq_rec[i0 + i];
         seq_fuse_pairs(a.L, a.n, B, nullptr, c->seq_xch != nullptr && (c->seq_grid >> 3) % 2 == 0 && (c->seq_grid >> 4) <= SEQ_XCH_PAIRS);   // (a pair never straddles two launches)
         seq_fuse_triples(a.L, a.n, B, c->seq_wstd.data() + i0);
+        seq_mark_resident(a.L, a.n, B, c->seq_grid >> 3, c->buf.count("p2") ? c->buf.at("p2") : nullptr);
         const char *ck = getenv("SMK_SEQ_CLK");
         const bool want_clk = ck != nullptr && !c->graph_mode;
         // SMK_SEQ_CLK=2: additionally the phases INSIDE the first tile of every layer (a separate kernel build with the stamps)
@@ -2455,14 +2504,28 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "wreg_policy")) { if (value != 0 && value != 1) return fail(SMK_E_ARG, "wreg_policy 0|1"); g_tune.wreg_policy = value; }
     else if (!strcmp(key, "npw")) { if (value != 2 && value != 4) return fail(SMK_E_ARG, "npw 2|4"); g_tune.npw = value; }
     else if (!strcmp(key, "mask_overlap")) g_tune.mask_overlap = value != 0;
+#ifdef SMK_MEASURE
     else if (!strcmp(key, "pipe_eager")) g_tune.pipe_eager = value & 3;
     else if (!strcmp(key, "pipe_join")) g_tune.pipe_join = value != 0;
-    else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
-    else if (!strcmp(key, "front_occ1")) g_tune.front_occ1 = value & 3;
-    else if (!strcmp(key, "pp")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pp 0..2"); g_tune.pp = value; }
-    else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
     else if (!strcmp(key, "pipe_two_form")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_two_form 0..2"); g_tune.pipe_two_form = value; }
     else if (!strcmp(key, "pipe_sig")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_sig 0..2"); g_tune.pipe_sig = value; }
+#else
+    else if (!strcmp(key, "pipe_eager") || !strcmp(key, "pipe_join") || !strcmp(key, "pipe_two_form") || !strcmp(key, "pipe_sig")) {
+        const int dflt = !strcmp(key, "pipe_eager") ? 0 : (!strcmp(key, "pipe_join") ? 1 : (!strcmp(key, "pipe_two_form") ? 1 : 2));
+        if (value != dflt) return fail(SMK_E_ARG, "%s: the measured alternatives of the pipelined step are only in a library built with `make MEASURE=1`", key);
+    }
+#endif
+    else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "front_occ1")) {
+#ifdef SMK_MEASURE
+        g_tune.front_occ1 = value & 3;
+#else
+        if (value) return fail(SMK_E_ARG, "front_occ1: a measured loss (profiles/r06g_front_occupancy_ab.txt), only in a library built with `make MEASURE=1`");
+#endif
+    }
+    else if (!strcmp(key, "seq_yres")) g_tune.seq_yres = value != 0;
+    else if (!strcmp(key, "pp")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pp 0..2"); g_tune.pp = value; }
+    else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
     else if (!strcmp(key, "prio")) { if (value < -1 || value > 3) return fail(SMK_E_ARG, "prio -1..3"); g_tune.prio = value; }
     else if (!strcmp(key, "kt")) { if (value != 0 && value != 128 && value != 256) return fail(SMK_E_ARG, "kt 0|128|256"); g_tune.kt = value; }
@@ -2481,7 +2544,7 @@ int smk_tune_get(const char *key, int *value) {
         return 0;
     }
     static const struct { const char *name; int *slot; } knobs[] = {
-        {"seq_fused_last", &g_seq_fused_last},
+        {"seq_fused_last", &g_seq_fused_last}, {"seq_yres_last", &g_seq_yres_last},
         {"xcd_mode", &g_tune.xcd_mode}, {"force_tile", &g_tune.force_tile}, {"min_blocks_x16", &g_tune.min_blocks_x16},
         {"concurrency", &g_concurrency_default}, {"stages", &g_tune.stages}, {"merge", &g_tune.merge}, {"merge_max_batch", &g_tune.merge_max_batch}, {"seq_spoll", &g_tune.seq_spoll}, {"rf_wreg", &g_tune.rf_wreg}, {"seq_fuse3", &g_tune.seq_fuse3}, {"seq_fused3_last", &g_seq_fused3_last},
         {"nchw_tn_major", &g_tune.nchw_tn_major}, {"chain_mask", &g_tune.chain_mask}, {"wreg", &g_tune.wreg},
@@ -2490,7 +2553,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2619,7 +2682,7 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
     c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
                         c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
                         (B <= 16 ||   // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
-                         (c->pipe_two && g_tune.pipe_two_form == 1));      // depth-2 pipelining, form 1: the tail's first part launches it (step_tail)
+                         (c->pipe_two && PIPE_TWO_FORM == 1));      // depth-2 pipelining, form 1: the tail's first part launches it (step_tail)
     int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, defer_mask_join, phase);
     c->defer_mask_req = false;
     CHK(rc2);
@@ -2639,7 +2702,7 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
 static int step_tail(smk_ctx *c, int B, float *mask, double *box_out, float *refine_out, hipStream_t st, int part = 0) {
     c->ring_in_step = c->ring_rows > 0;
     c->ring_step_refine = refine_out != nullptr && c->ring_ref != nullptr;
-    if (part == 1 && c->have_deferred_mask && g_tune.pipe_two_form == 1) {
+    if (part == 1 && c->have_deferred_mask && PIPE_TWO_FORM == 1) {
         // depth-2 pipelining: the 63x63 mask head FIRST (it needs head0 only) -- as its own launch beside the next frame's front end; inside
         // the chain launch of part 2 its 640 tiles would take the CUs from that frame's conv_search (measured: 67 instead of 32 us,
         // profiles/r05j_depth2_chain_mask_beside_heads.txt); the chain alone (one workgroup per stream) runs there for free
@@ -2701,9 +2764,9 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     memcpy(&pk, &c->penalty_k, 8); memcpy(&wi, &c->window_influence, 8);
     const std::vector<const void *> io{x, target_wh, cls, loc, mask, box_out, refine_out, (const void *)pk, (const void *)wi};
     const bool graphs = c->graph_mode;
-    const bool gate = g_tune.pipe_join != 0;
-    const bool sig = gate && g_tune.pipe_sig == 1 && c->pipe_sig;
-    const bool tgate = gate && g_tune.pipe_sig == 2;      // the tail's start is a gate kernel too (A/B)
+    const bool gate = PIPE_JOIN != 0;
+    const bool sig = gate && PIPE_SIG == 1 && c->pipe_sig;
+    const bool tgate = gate && PIPE_SIG == 2;      // the tail's start is a gate kernel too (A/B)
     // where the main gate sits: in front of layer2 when that is the persistent sequence (it must own every CU), else in front of the
     // heads -- the first launches that write what the tail reads (smk_tune pipe_late = 0 keeps it in front of layer2 for the A/B)
     const bool late = gate && g_tune.pipe_late && !(seq_wanted(c, B) && !parallel_ok(c));
@@ -2712,9 +2775,9 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     // (the Refine chain + the mask head: one low-occupancy launch of ~50 us that only reads part 1's outputs and head0) waits for the
     // next frame's persistent launch to LEAVE and runs beside that frame's heads (conv_search / corr_head / decode leave 40-200 CUs
     // idle) -- it is launched by the NEXT smk_step, or without its gate by whatever joins the pipeline first.
-    const bool two = c->pipe_depth >= 2 && graphs && gate && tgate && !late && !sig && refine_splittable(c, B) && !g_tune.pipe_eager;
+    const bool two = c->pipe_depth >= 2 && graphs && gate && tgate && !late && !sig && refine_splittable(c, B) && !PIPE_EAGER;
     const int fl = flags | (par << 16) | (gate ? 1 << 17 : 0) | (sig ? 1 << 18 : 0) | (tgate ? 1 << 19 : 0) | (late ? 1 << 20 : 0) | (two ? 1 << 21 : 0) |
-                   ((two && g_tune.pipe_two_form == 1) ? 1 << 22 : 0) | ((two && g_tune.pipe_two_form == 2) ? 1 << 23 : 0);
+                   ((two && PIPE_TWO_FORM == 1) ? 1 << 22 : 0) | ((two && PIPE_TWO_FORM == 2) ? 1 << 23 : 0);
     const GraphKey kf{10, B, fl, io}, km{11, B, fl, io}, kt{12, B, fl, io}, kt2g{13, B, fl, io}, kt2n{14, B, fl, io};
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
@@ -2729,7 +2792,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         c->pipe_two = two;
         // the "chip is free for the previous frame's second tail part" semaphore: raised by the persistent launch's last leaving team
         // (forms 0 / 1) or by corr_head's first workgroup, i.e. behind conv_search (form 2)
-        c->pipe_seq_exit = two && g_tune.pipe_two_form != 2; c->pipe_corr_sem = two && g_tune.pipe_two_form == 2; c->pipe_seq_exit_done = false;
+        c->pipe_seq_exit = two && PIPE_TWO_FORM != 2; c->pipe_corr_sem = two && PIPE_TWO_FORM == 2; c->pipe_seq_exit_done = false;
         const int rcm = mid(st);
         c->pipe_corr_sem = false;
         c->pipe_mark_fold = false;
@@ -2767,9 +2830,9 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         if (two) {
             // (pipe_two_form 1: part 1 launches the mask head itself and part 2 is the bare chain; 0: the chain launch of part 2 carries it)
             CHK(capture_graph(c, kt, [&](hipStream_t st) { return tail(st, 1, true); }));
-            c->have_deferred_mask = hm && g_tune.pipe_two_form != 1;
+            c->have_deferred_mask = hm && PIPE_TWO_FORM != 1;
             CHK(capture_graph(c, kt2g, [&](hipStream_t st) { return tail(st, 2, true); }));
-            c->have_deferred_mask = hm && g_tune.pipe_two_form != 1;
+            c->have_deferred_mask = hm && PIPE_TWO_FORM != 1;
             CHK(capture_graph(c, kt2n, [&](hipStream_t st) { return tail(st, 2, false); }));
             c->have_deferred_mask = false;
         } else {
@@ -2786,7 +2849,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         // (no event wait on `s`: the gate inside main(f) is the join; tail_ev stays for the serial entry points and smk_pipeline_join)
         c->tail_pending = false;
     } else {
-        CHK((graphs && !(g_tune.pipe_eager & 1)) ? launch_graph(c, kf, s) : front(s));
+        CHK((graphs && !(PIPE_EAGER & 1)) ? launch_graph(c, kf, s) : front(s));
         CHK(pipe_join(c, s, true));
         CHK(graphs ? launch_graph(c, km, s) : mid(s));
     }
@@ -2815,7 +2878,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
         c->tail2_pending = true;
         c->tail2_key = kt2n;
         c->tail2_gated_key = kt2g;
-    } else if (graphs && !(g_tune.pipe_eager & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
+    } else if (graphs && !(PIPE_EAGER & 2)) CHK(launch_graph(c, kt, c->pipe_stream));
     else {
         // (eager: the capture-time hand-over of the mask head is replayed from the context, see step_track_decode)
         if (graphs) c->have_deferred_mask = c->pipe_tail_has_mask;
@@ -2876,6 +2939,18 @@ int smk_set_pipeline(smk_ctx *c, int depth) {
     CHK(pipe_quiesce(c));
     HIPCHK(hipDeviceSynchronize());
     c->tail_pending = false;
+    if (depth > 0) {
+        // The tail's gate polls on the side stream WHILE the step's own kernels run on the caller's stream.  With ONE hardware queue
+        // (GPU_MAX_HW_QUEUES=1) both streams share it: the gate sits in front of the very work it waits for, stalls for its 5 s limit
+        // and raises SMK_E_SEQ.  Detect, don't stall: serial steps (same bits), said once.
+        const char *hq = getenv("GPU_MAX_HW_QUEUES");
+        if (hq && *hq && atoi(hq) < 2) {
+            static bool said = false;
+            if (!said) fprintf(stderr, "siammask_hip: GPU_MAX_HW_QUEUES=%s -- the pipelined frame step needs two hardware queues; running serial steps\n", hq);
+            said = true;
+            depth = 0;
+        }
+    }
     if (depth > 0) {
         if (!c->buf.count("p0#1")) {
             CHK(alloc_buf(c, "p0#1", c->buf_elems.at("p0")));
@@ -3249,6 +3324,9 @@ int smk_op_conv_seq(const smk_seq_op *ops, int n, const float *x_dev, int iters,
         std::vector<const void *> wstd(n);
         for (int i = 0; i < n; ++i) wstd[i] = packs[i].w_frag;
         seq_fuse_triples(a.L, a.n, B, wstd.data(), &locked);
+        std::vector<char> keep(n, 0);
+        for (int i = 0; i < n; ++i) keep[i] = ops[i].y_dev != nullptr;
+        seq_mark_resident(a.L, a.n, B, grid >> 3, nullptr, &keep);
     }
     if (n_fused_out) {
         *n_fused_out = 0;

@@ -256,9 +256,14 @@ int launch_l1_block(const L1BlockParams &p, void *stream) {
     if (p.K1pad < p.Cin || p.K2pad < 576 || p.K3pad < 64 || (p.K1pad | p.K2pad | p.K3pad | p.Kdpad) % 32) return -1;
     const int tpr = (p.S + LB_T - 1) / LB_T;
     const dim3 grid(p.B * tpr * tpr), block(256);
-    // smk_tune "front_occ1" bit 0 (A/B knob): unused dynamic LDS on top of the static 72 / 76 KB, so that ONE workgroup owns a CU and the
-    // other half of its LDS and registers stays free for another stream's kernels (the pipelined step's tail)
+    // smk_tune "front_occ1" bit 0 (A/B knob of MEASURE builds): unused dynamic LDS on top of the static 72 / 76 KB, so that ONE workgroup owns
+    // a CU and the other half of its LDS and registers stays free for another stream's kernels (the pipelined step's tail).  Measured:
+    // +3.5 % per step -- the tail does not use what is freed (profiles/r06g_front_occupancy_ab.txt).
+#ifdef SMK_MEASURE
     const unsigned pad = (g_tune.front_occ1 & 1) ? (p.Cin == 64 ? 12288u : 8192u) : 0u;
+#else
+    const unsigned pad = 0u;
+#endif
     if (p.Cin == 64) hipLaunchKernelGGL(l1_block_kernel<64>, grid, block, pad, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(l1_block_kernel<256>, grid, block, pad, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;

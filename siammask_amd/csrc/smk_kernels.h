@@ -101,7 +101,7 @@ struct SeqLayer {
     signed char cfg;       // workgroup tile: 0 = 64x256, 1 = 64x128, 2 = 64x64, 3 = 128x256, 4 = 128x128, 9 = 128x64;
                            //   measurement variants: 5 = 64x128 with a 5-deep ring and weights 4 K tiles ahead, 6..8 ablations
     signed char sync;      // 1: the next layer reads what this one (or an earlier one since the last barrier) wrote
-    signed char a_stage;   // see ConvParams::a_stage
+    signed char a_stage;   // bit 0: see ConvParams::a_stage; bits 1-3 (engine.cpp seq_mark_resident, round 6): SEQ_YRES_IN / _NOSTORE / SEQ_LDS_HI
     signed char kstag;     // 1: every workgroup starts its K loop at another K tile (see wreg_tile kt0)
     signed char res_nt;    // 1: residual rows are fetched non-temporally (the tensor is dead after this layer)
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
@@ -130,6 +130,12 @@ constexpr size_t SEQ_XCH_BYTES = (size_t)8 * SEQ_XCH_PAIRS * 4 * SEQ_XCH_SLAB;
 // the record's wgt_frag points at the chunk-major fragment pack (PackedConv::w_frag_halo)
 constexpr int SEQ_CFG_HALO128 = 24;    // 128 pixels (whole output rows) x 64 channels
 constexpr int SEQ_CFG_HALO64 = 25;     // 64 pixels x 64 channels
+// Resident trunk (round 6): with one image per team a layer's fused pairs run on the SAME 32 rows in the SAME workgroup, Bottleneck after
+// Bottleneck, so the pair's LDS image Y (relu(conv3 + residual), the next block's residual) stays where it is: the next pair does not
+// fetch it back (SEQ_YRES_IN), this pair does not store it (SEQ_YRES_NOSTORE: nobody else reads the tensor), and the 3x3 convolution
+// in between works in the LDS above it (SEQ_LDS_HI on its record; its 128-row epilogue then runs in two halves).
+constexpr int SEQ_YRES_IN = 2, SEQ_YRES_NOSTORE = 4, SEQ_LDS_HI = 8;
+constexpr int SEQ_YRES_BYTES = 65536;  // [32][1024] f16: the largest Y image (layer3); the routines between two pairs start here
 constexpr int SEQ_MAX = 36;
 struct SeqArgs {
     int n, B;
@@ -202,6 +208,8 @@ struct Tuning {
     int pair_launch = 1;       // fp16, batches outside the persistent sequence: a Bottleneck's conv3 + the next 1x1 convolution as ONE launch
                                // (conv_pair_kernel = c3c1_tile per 32 rows of the flattened batch); 0 = two launches, 1 = the measured rule (off for B <= 2, 32-row tiles to B = 8, 64-row tiles -- c3c1s_tile -- from B = 9), 2 / 3 = always 32 / 64 rows
     int corr_head = 1;         // fp16: dw_xcorr + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); 0 = the three launches of rounds 1-3
+    int seq_yres = 1;          // sequences, batches of at most 8 (one image per team): the fused pairs' trunk image Y stays in LDS from Bottleneck to
+                               // Bottleneck (no 64 KB re-fetch per CU and pair, no store of a tensor only the same workgroup reads); bit-identical
     int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
                                // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
                                // exchanged): 0 = c3c1_tile (one CU, 32 rows, all channels), 1 = every pair, 2 = layer3's pairs only
@@ -217,8 +225,8 @@ struct Tuning {
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
     int pp = 1;                // fp16 NHWC convolutions with M >= 32768 rows, K >= 2304 and >= 200 tiles of 256 x 256 through conv_pp_kernel (0 off, 1 the
                                // rule in engine.cpp pp_choice, 2 wherever eligible)
-    int front_occ1 = 0;        // A/B knob: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
-                               // step's tail run BESIDE the next frame's front end then, instead of taking turns with it?
+    int front_occ1 = 0;        // MEASURE builds: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
+                               // step's tail run BESIDE the next frame's front end then?  No: +3.5 % per step (profiles/r06g_front_occupancy_ab.txt)
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)

@@ -137,7 +137,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
 int launch_stem_pool(const StemPoolParams &p, void *stream) {
     if (p.Kpad < SP_KS * 16 || !p.wgt_frag || !p.bias || p.s0 != (p.S - 7) / 2 + 1 || p.s1 != (p.s0 - 1) / 2 + 1) return -1;
     const int tpr = (p.s1 + SP_TP - 1) / SP_TP;
-    const unsigned pad = (g_tune.front_occ1 & 2) ? 32768u : 0u;      // (A/B knob, see Tuning::front_occ1: one workgroup per CU)
+#ifdef SMK_MEASURE
+    const unsigned pad = (g_tune.front_occ1 & 2) ? 32768u : 0u;      // (A/B knob, see Tuning::front_occ1: one workgroup per CU; measured a loss)
+#else
+    const unsigned pad = 0u;
+#endif
     hipLaunchKernelGGL(stem_pool_kernel, dim3(p.B * tpr * tpr), dim3(256), pad, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

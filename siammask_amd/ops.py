@@ -83,7 +83,8 @@ def conv_seq(x, layers, iters=1, want_outputs=True, info=None):
     src (-1 = x, j = output of layer j; default: the previous layer), res (source index of the residual, -1 = x) with
     res_mode 1 (before the ReLU) / 2 (after), sync (default True), tile ((bm, bn), "deep" or None), kstag (-1 engine's choice).
     Returns (outputs [list of float32 NCHW tensors], usec per launch, per-layer (tiles_us, arrive_us) array); info (a dict,
-    optional) receives "fused_pairs" = the (conv3, next 1x1) pairs the launch ran as one tile routine (smk_tune "seq_fuse")."""
+    optional) receives "fused_pairs" = the (conv3, next 1x1) pairs the launch ran as one tile routine (smk_tune "seq_fuse").
+    want_outputs: True (all layers), False, or a collection of layer indices (the returned list then holds None elsewhere)."""
     _chk_cuda(x)
     x = x.contiguous().float()
     B = x.shape[0]
@@ -114,11 +115,13 @@ def conv_seq(x, layers, iters=1, want_outputs=True, info=None):
         arr[i].kstag = l.get("kstag", -1)
         arr[i].w_host = w.ctypes.data
         arr[i].b_host = b.ctypes.data if b is not None else None
-        if want_outputs:
+        if want_outputs is True or (want_outputs not in (False, None) and i in want_outputs):
             y = torch.empty((B, w.shape[0], Ho, Wo), dtype=torch.float32, device=x.device)
             outs.append(y)
             arr[i].y_dev = y.data_ptr()
         else:
+            if want_outputs not in (True, False, None):
+                outs.append(None)              # (a collection of layer indices: the other layers' outputs are not read back)
             arr[i].y_dev = None
     us = ctypes.c_float(0.0)
     clk = np.zeros(2 * n, dtype=np.float32)

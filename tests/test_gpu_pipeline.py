@@ -111,6 +111,11 @@ def test_other_join_forms_are_the_same_arithmetic(knobs):
     of the gate that polls beside the persistent launch; pipe_sig = 1 -- hipStreamWaitValue32 on signal memory; pipe_eager = 2 -- the
     tail as eager launches; pipe_two_form = 0 / 2 -- depth 2 with chain + mask head as ONE launch behind the persistent launch /
     behind conv_search (profiles/r05j_*, r05o_*).  Same rows."""
+    if not _lib.tune_get("measure_build"):
+        # round 6 (VERDICT r5 #7): the forms that measured slower are compiled by `make MEASURE=1` only; the product library refuses them
+        with pytest.raises(RuntimeError):
+            _lib.tune(**knobs)
+        pytest.skip("the measured alternatives of the pipelined step are only in a library built with `make MEASURE=1`")
     old = {k: _lib.tune_get(k) for k in knobs}
     try:
         _lib.tune(**knobs)
@@ -217,3 +222,43 @@ def test_ring_batch_is_recorded_by_the_library():
     assert L.smk_set_result_ring(m._ctx, box.data_ptr(), None, 2, 9) == -1     # beyond max_batch
     _lib.check(L.smk_set_result_ring(m._ctx, None, None, 0, 0))
     torch.cuda.synchronize()
+
+
+def test_pipelined_ring_rows_against_the_oracle():
+    """VERDICT r5 (weak #3): every other test of this file compares pipelined rows with serial rows, and the serial step with the oracle
+    elsewhere.  Here the ring rows of three free-running PIPELINED frames at the bench's batch are held against the oracle directly:
+    fp16 context vs the quantisation-aware oracle (the fp16 gate of tests/test_gpu_e2e.py, 5e-3), the Refine logits at the positions
+    the device decoded (its fp16 argmax may legitimately differ from the fp64 one), the box row's index / score against
+    decode_best of the oracle's own cls / loc on the streams where both pick the same anchor."""
+    from oracle.np_oracle import QuantOracle, decode_best
+    from helpers import rel_err
+    B, frames = 8, 3
+    m = _model(B, "f16")
+    z, xs, twh = _inputs(B, frames, 731)
+    m.template(z)
+    box, ref = m.set_result_ring(frames, batch=B)
+    m.set_pipeline(1)
+    for x in xs:
+        m.track_step(x, twh, refine=True, stage=False)       # free-running: no synchronisation between the frames
+    m.pipeline_join()
+    torch.cuda.synchronize()
+    assert m.result_ring_frames() == frames and m.seq_status() == (256, 0)
+    o = QuantOracle(synth.state_dict("sharp", "synthetic_damped"), "sharp")
+    o.template(z.cpu().numpy().astype(np.float64))
+    twh_h = twh.cpu().numpy()
+    same = 0
+    for f, x in enumerate(xs):
+        ocls, oloc, _ = o.track_mask(x.cpu().numpy().astype(np.float64))
+        row = box[f].cpu().numpy()
+        best = row[:, 7].astype(np.int64)
+        oref = o.track_refine(np.stack([(best % 625) // 25, best % 25], 1))
+        e = rel_err(ref[f].float().cpu().numpy().reshape(B, -1), oref.reshape(B, -1))
+        assert e <= 5e-3, "frame %d: pipelined ring logits vs the oracle %.2e" % (f, e)
+        for b in range(B):
+            bid, _, _, ps = decode_best(ocls[b], oloc[b], target_sz=twh_h[b], scale_x=1.0)
+            if bid == best[b]:
+                same += 1
+                assert abs(row[b, 6] - ps[bid]) <= 5e-3 * max(1.0, abs(ps[bid])), (f, b, row[b, 6], ps[bid])
+            else:       # an fp16 pick: still one of the oracle's near-best candidates
+                assert ps[best[b]] >= ps[bid] - 2e-2, (f, b, best[b], bid, ps[best[b]], ps[bid])
+    assert same >= int(0.8 * B * frames), same

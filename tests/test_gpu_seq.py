@@ -625,3 +625,46 @@ def test_scalar_path_poll_gives_the_same_bits_and_clean_counters(B):
         _lib.tune(seq_spoll=old)
     for k in outs[1]:
         assert torch.equal(outs[1][k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("shape,B,S", [((1024, 256), 8, 31), ((1024, 256), 3, 15), ((512, 128), 8, 31), ((512, 128), 5, 15)])
+def test_conv_seq_resident_trunk_gives_the_same_bits(shape, B, S):
+    """Round 6 (smk_tune "seq_yres"): with one image per team the fused pairs of a ResNet layer run on the same 32 rows in the same
+    workgroup, Bottleneck after Bottleneck (resnet.py:80-103), so the second pair finds its residual -- the Y image the first one
+    built -- still in LDS: no re-fetch, no store of a tensor nobody else reads, the 3x3 convolution in between works in the LDS
+    behind the image (its 128-row accumulator hand-over in two halves).  Nothing about the arithmetic changes: every output must be
+    BIT-identical to the list without the marks, with every tensor read back (Y stored) and with only the last one (Y never
+    leaves the CUs); at B = 10 (two images on some teams) nothing may be marked."""
+    from siammask_amd import _lib
+    ops = _ops()
+    cin, planes = shape
+    rng = np.random.default_rng(606 + S + cin)
+    x = rng.uniform(-1, 1, size=(B, cin, S, S)).astype(np.float32)
+    layers = _chain(rng, cin, planes, 3, 2 if cin == 1024 else 1)
+    xd = torch.from_numpy(x).cuda()
+    old = _lib.tune_get("seq_yres")
+    try:
+        _lib.tune(seq_yres=0)
+        ref, _, _ = ops.conv_seq(xd, layers)
+        assert _lib.tune_get("seq_yres_last") == 0
+        _check(x, layers, ref, "chain without the marks")
+        _lib.tune(seq_yres=1)
+        info = {}
+        got, us, clk = ops.conv_seq(xd, layers, iters=3, info=info)
+        assert info["fused_pairs"] == 3 and _lib.tune_get("seq_yres_last") == 2, (info, _lib.tune_get("seq_yres_last"))
+        for i, (u, v) in enumerate(zip(ref, got)):
+            assert torch.equal(u, v), (i, float((u - v).abs().max()))
+        last = len(layers) - 1
+        only, _, _ = ops.conv_seq(xd, layers, iters=3, want_outputs=(last,))
+        assert _lib.tune_get("seq_yres_last") == 2
+        assert torch.equal(only[last], ref[last]), float((only[last] - ref[last]).abs().max())
+        # two images on a team: a workgroup owns two tiles per pair, Y cannot stay
+        x10 = rng.uniform(-1, 1, size=(10, cin, 15, 15)).astype(np.float32)
+        a10, _, _ = ops.conv_seq(torch.from_numpy(x10).cuda(), layers, want_outputs=(last,))
+        assert _lib.tune_get("seq_yres_last") == 0
+        _lib.tune(seq_yres=0)
+        b10, _, _ = ops.conv_seq(torch.from_numpy(x10).cuda(), layers, want_outputs=(last,))
+        assert torch.equal(a10[last], b10[last])
+    finally:
+        _lib.tune(seq_yres=old)
+    print("resident trunk %s B=%d S=%d: %.1f us per launch; per layer (tiles us): %s" % (shape, B, S, us, np.round(clk[:, 0], 1).tolist()))
