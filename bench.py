@@ -47,10 +47,12 @@ WORKLOADS = {
     "sharp_b16_f16": ("sharp", 16, "f16", True),    # two streams per XCD in the persistent sequence
     "sharp_b64_f16": ("sharp", 64, "f16", True),    # configs[4] regime (per GPU)
     "sharp_b8_f32": ("sharp", 8, "f32", True),
+    "sharp_b8_f16x3": ("sharp", 8, "f16x3", True),  # split-operand fp16: the oracle's argmax box index on the fp16 matrix pipe (round 6)
     "base_b1_f32": ("base", 1, "f32", False),       # BASELINE configs[1]
     "rpn_b1_f32": ("rpn", 1, "f32", False),         # BASELINE configs[0] shape on the GPU
 }
-PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3}        # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f16": 2500.0, "f32": 157.3,        # dense MFMA peaks, MI355X_MICROARCH.md
+               "f16x3": 2500.0 / 3.0}              # three fp16 MFMA products per algorithmic multiply-accumulate
 
 
 def make_model(variant, dtype, batch, device):
@@ -831,7 +833,7 @@ def main():
 
     also = {}
     if rank == 0 and world == 1 and not args.no_also and not args.stub:
-        for name in ("sharp_b8_f32", "base_b1_f32", "sharp_b1_f16", "sharp_b16_f16", "sharp_b64_f16"):
+        for name in ("sharp_b8_f32", "sharp_b8_f16x3", "base_b1_f32", "sharp_b1_f16", "sharp_b16_f16", "sharp_b64_f16"):
             if name == args.workload:
                 continue
             try:

@@ -38,6 +38,11 @@ typedef struct smk_ctx smk_ctx;
 /* arithmetic type of activations / weights on the device (accumulation is always fp32) */
 #define SMK_DTYPE_F32 0
 #define SMK_DTYPE_F16 1
+/* ABI 1.6: split-operand fp16.  Every value of the track path's trunk (stem .. cls / loc head.3) is a pair of fp16 planes hi + lo and a
+ * product the three MFMA products hi*hi + hi*lo + lo*hi in the fp32 accumulator: fp32-grade cls / loc / box -- the argmax box index of the
+ * fp64 reference (/root/reference/tools/test.py:237) on every stream of tests/golden/argmax_oracle_1024.npz -- on the fp16 matrix pipe.
+ * The mask head and Refine run in plain fp16 on the hi planes (their gates are the fp16 context's). */
+#define SMK_DTYPE_F16X3 2
 
 /* network variant = which reference experiment's Custom is being replaced */
 #define SMK_VARIANT_RPN   0   /* experiments/siamrpn_resnet/custom.py:81-93  */

@@ -18,7 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMK_LIB") or os.path.join(_HERE, "libsiammask_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "half": 1}
+DTYPE = {"f32": 0, "fp32": 0, "float32": 0, "f16": 1, "fp16": 1, "float16": 1, "half": 1,
+         "f16x3": 2}       # split-operand fp16 (SMK_DTYPE_F16X3): fp32-grade cls / loc / box on the fp16 matrix pipe
 VARIANT = {"rpn": 0, "base": 1, "sharp": 2}
 TRACK_BOX, TRACK_MASK, TRACK_NO_MASK_HEAD = 0, 1, 2
 

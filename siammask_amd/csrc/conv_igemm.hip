@@ -267,7 +267,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
             g_Hs = sgpr(p.Hs), g_Ws = sgpr(p.Ws), g_Cs = sgpr(p.Cs), g_cish = sgpr(p.ci_shift), g_Ci = sgpr(p.Ci), g_ups = sgpr(p.ups);
         asm volatile("" : "+s"(g_kwm), "+s"(g_kw), "+s"(g_kh), "+s"(g_dil), "+s"(g_Hl), "+s"(g_Wl));
         asm volatile("" : "+s"(g_Hs), "+s"(g_Ws), "+s"(g_Cs), "+s"(g_cish), "+s"(g_Ci), "+s"(g_ups));
-        const bool tap_uniform = g_cish >= 0 && g_Ci >= BK;
+        // (round 6: a K tile never straddles a tap whenever Ci is a MULTIPLE of the tile, power of two or not -- the split-operand
+        //  packs have Ci = 3 x 2^s; the tap is then one division per tile on wave-uniform values instead of one per lane and row)
+        const bool tap_uniform = g_Ci >= BK && (g_cish >= 0 || (g_Ci % BK) == 0);
         int cur_tap_s = -1;                                // wave-uniform tap of the last decode
         int cur_c = 0;
         long a_off[RA];                                    // byte offsets relative to `in`
@@ -295,8 +297,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
         auto set_tile = [&](int kt) {
             if (tap_uniform) {
                 const int k0 = kt * BK;
-                const int tap = k0 >> g_cish;
-                cur_c = (k0 & (g_Ci - 1)) + slot * VE;
+                const int tap = g_cish >= 0 ? k0 >> g_cish : k0 / g_Ci;
+                cur_c = (g_cish >= 0 ? (k0 & (g_Ci - 1)) : k0 - tap * g_Ci) + slot * VE;
                 if (tap != cur_tap_s) {
                     cur_tap_s = tap;
                     tap_offsets(tap);
@@ -450,7 +452,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + r0, m = m0 + row;
-                if (row < BM && m < p.M) TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + n0 + c4, rv[ps]);
+                if (row < BM && m < p.M) {
+                    TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + n0 + c4, rv[ps]);
+                    if constexpr (sizeof(T) == 2) {
+                        if (p.x3_res > 0) {                    // split residual (DT_F16X3): value = hi + lo
+                            float lo[EV];
+                            TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + 2 * p.x3_res + n0 + c4, lo);
+#pragma unroll
+                            for (int q = 0; q < EV; ++q) rv[ps][q] += lo[q];
+                        }
+                    }
+                }
             }
         }
     }
@@ -549,11 +561,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
             if (tid == 0) __hip_atomic_store(p.ks_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
         }
         if (ncol_ok) {
-            float bv[EV];
+            float bv[EV], osc[EV];
 #pragma unroll
             for (int q = 0; q < EV; q += 4) {
                 const floatx4 b4 = *(const floatx4 *)(bias + n + q);
                 bv[q] = b4[0]; bv[q + 1] = b4[1]; bv[q + 2] = b4[2]; bv[q + 3] = b4[3];
+                osc[q] = osc[q + 1] = osc[q + 2] = osc[q + 3] = 1.f;
+                if (p.oscale) {                            // (DT_F16X3: the power-of-two row scale of the split pack, undone exactly)
+                    const floatx4 s4 = *(const floatx4 *)(p.oscale + (bias - p.bias) + n + q);
+                    osc[q] = s4[0]; osc[q + 1] = s4[1]; osc[q + 2] = s4[2]; osc[q + 3] = s4[3];
+                }
             }
             T *out = (T *)p.out;
 #pragma unroll
@@ -564,13 +581,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
                     float v[EV];
 #pragma unroll
                     for (int q = 0; q < EV; ++q) {
-                        float x = vv[ps][q] + bv[q];
+                        float x = vv[ps][q] * osc[q] + bv[q];
                         if (p.res_mode == RES_PRE_RELU) x += rv[ps][q];
                         if (p.relu) x = fmaxf(x, 0.f);
                         if (p.res_mode == RES_POST_RELU) x += rv[ps][q];
                         v[q] = x;
                     }
                     TR::storev(out + (size_t)m * p.Cos + cout_off + n, v);
+                    if constexpr (sizeof(T) == 2) {
+                        if (p.x3_out > 0) {                    // split output (DT_F16X3): [hi | hi | lo = v - hi]
+                            float lo[EV];
+#pragma unroll
+                            for (int q = 0; q < EV; ++q) lo[q] = v[q] - (float)(_Float16)v[q];
+                            TR::storev(out + (size_t)m * p.Cos + cout_off + p.x3_out + n, v);
+                            TR::storev(out + (size_t)m * p.Cos + cout_off + 2 * p.x3_out + n, lo);
+                        }
+                    }
                 }
             }
         }
@@ -598,8 +624,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
                     floatx4 v = *(const floatx4 *)ec;
 #pragma unroll
                     for (int q = 1; q < WK; ++q) v += *(const floatx4 *)(ec + q * (64 * LDE));
-                    const float bn = bias[n];
-                    v[0] += bn; v[1] += bn; v[2] += bn; v[3] += bn;
+                    const float bn = bias[n], sn = p.oscale ? p.oscale[(bias - p.bias) + n] : 1.f;
+                    v[0] = v[0] * sn + bn; v[1] = v[1] * sn + bn; v[2] = v[2] * sn + bn; v[3] = v[3] * sn + bn;
                     if (p.relu) {
                         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
                         v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);

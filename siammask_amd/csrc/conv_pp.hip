@@ -350,7 +350,7 @@ void conv_pp_kernel(const ConvParams p) {
 bool conv_pp_eligible(const ConvParams &p, int dtype) {
     return dtype == DT_F16 && p.out_mode == OUT_NHWC && p.wgt != nullptr && p.buf_lds && (p.Kpad % 128) == 0 && p.groups <= 1 &&
            p.ci_shift >= 6 && !p.ups && !p.pos && p.org_y == 0 && p.org_x == 0 && p.Hl == p.Hs && p.Wl == p.Ws &&
-           p.in_bytes < 0x7fff0000u && p.w_bytes < 0x7fff0000u && (p.Nst % 8) == 0;
+           p.in_bytes < 0x7fff0000u && p.w_bytes < 0x7fff0000u && (p.Nst % 8) == 0 && !p.x3_out && !p.x3_res;
 }
 
 int launch_conv_pp(const ConvParams &p, void *stream) {

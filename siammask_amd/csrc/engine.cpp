@@ -107,6 +107,8 @@ struct PackedConv {
     int Ci = 0, k = 1, K = 0, Kpad = 0;
     int kw = 0;              // horizontal taps when != k (pixel-pair stem)
     int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
+    float *oscale = nullptr; // DT_F16X3: device [rows] f32, the inverse of the power-of-two scale each row of the split pack carries (ConvParams::oscale)
+    bool x3 = false;         // DT_F16X3: K tripled -- per tap [w_hi | w_lo | w_hi] against activations stored [hi | hi | lo]; Ci = 3 x channels
 };
 
 constexpr size_t KS_PART_FLOATS = 8u << 20;      // 32 MB: e.g. 256 tiles x 4 parts x 64x128
@@ -125,7 +127,9 @@ constexpr size_t DEC_SCRATCH_PER_STREAM = 8 * 8 + 64 * 8 + 8 * 4 + 4;     // dec
 constexpr int PIPE_JOIN = 1, PIPE_SIG = 2, PIPE_EAGER = 0, PIPE_TWO_FORM = 1;
 #endif
 
-static size_t esize(int dtype) { return dtype == DT_F16 ? 2 : 4; }
+static size_t esize(int dtype) { return dtype == DT_F32 ? 4 : 2; }
+// DT_F16X3 contexts (smk_kernels.h): the KERNELS are the fp16 ones; what changes is which packs exist and how many channel planes a tensor has
+static int kdtype(int dtype) { return dtype == DT_F16X3 ? DT_F16 : dtype; }
 
 // host-side packing of ONE weight tensor [Cout][Cin][k][k] (already scaled) into rows of a
 // [rows][Kpad] matrix with K ordered (ky, kx, cin_padded)
@@ -407,8 +411,41 @@ static int fold(const smk_ctx *c, const ConvPart &part, int Cout, std::vector<do
 }
 
 // pack `parts` either N-fused (one group, rows concatenated) or as separate groups
+// x3 (DT_F16X3 contexts, the layers of the track path's trunk): per tap the Ci0 = rup(Cin, 8) channels three times -- [w_hi | w_lo | w_hi]
+// with w_hi = fp16(w), w_lo = fp16(w - w_hi) -- against activations stored as [hi | hi | lo] planes
+// Every row is first scaled by a power of two that takes its largest |w| into [2^13, 2^14): w_lo = fp16(s w - w_hi) is then a NORMAL fp16
+// number for every weight within 2^-16 of the row's maximum, i.e. the pair carries 22 bits where the unscaled, BN-folded weights (1e-2 .. 1e-3)
+// leave w_lo in the subnormals (3e-6 .. 3e-5 relative).  oscale[n] = 1 / s_n (exact); the epilogue multiplies the accumulator by it.
+static void split_rows_x3(std::vector<float> &rows, int nrows, int Kpad1, int Kpad3, int taps, int Ci0, std::vector<float> &oscale) {
+    std::vector<float> out((size_t)nrows * Kpad3, 0.f);
+    oscale.assign(nrows, 1.f);
+    for (int n = 0; n < nrows; ++n) {
+        float mx = 0.f;
+        for (int k = 0; k < taps * Ci0; ++k) mx = std::max(mx, std::fabs(rows[(size_t)n * Kpad1 + k]));
+        int e = 0;
+        if (mx > 0.f) {
+            e = 13 - (int)std::floor(std::log2(mx));                 // 2^e mx in [2^13, 2^14)
+            e = std::max(-8, std::min(e, 40));
+        }
+        const float sc = std::ldexp(1.f, e);
+        oscale[n] = std::ldexp(1.f, -e);
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < Ci0; ++ci) {
+                const float v = rows[(size_t)n * Kpad1 + (size_t)t * Ci0 + ci] * sc;
+                const float hi = (float)(_Float16)v, lo = (float)(_Float16)(v - hi);
+                float *d = out.data() + (size_t)n * Kpad3 + (size_t)t * 3 * Ci0 + ci;
+                d[0] = hi; d[Ci0] = lo; d[2 * Ci0] = hi;
+            }
+    }
+    rows.swap(out);
+}
+static int upload_oscale(PackedConv &pc, const std::vector<float> &oscale) {
+    HIPCHK(hipMalloc((void **)&pc.oscale, oscale.size() * 4));
+    HIPCHK(hipMemcpy(pc.oscale, oscale.data(), oscale.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
 static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPart> &parts, int Cin, int Cout,
-                     int k, bool grouped) {
+                     int k, bool grouped, bool x3 = false) {
     PackedConv pc;
     pc.Ci = rup(Cin, 8);
     pc.k = k;
@@ -437,8 +474,19 @@ static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPa
         pack_rows(rows, row0, pc.Kpad, w->data.data(), scale.data(), Cout, Cin, k, pc.Ci);
         for (int n = 0; n < Cout; ++n) bias[row0 + n] = (float)shift[n];
     }
-    CHK(upload_packed(pc, rows, bias, c->dtype));
-    if (!grouped) CHK(upload_halo_pack(pc, rows, c->dtype));
+    if (x3) {
+        const int Ci0 = pc.Ci, K1 = pc.Kpad;
+        pc.x3 = true;
+        pc.alg_k = k * k * Ci0;
+        pc.Ci = 3 * Ci0;
+        pc.K = k * k * pc.Ci;
+        pc.Kpad = rup(pc.K, KPAD_ALIGN);
+        std::vector<float> osc;
+        split_rows_x3(rows, pc.rows, K1, pc.Kpad, k * k, Ci0, osc);
+        CHK(upload_oscale(pc, osc));
+    }
+    CHK(upload_packed(pc, rows, bias, kdtype(c->dtype)));
+    if (!grouped && !x3) CHK(upload_halo_pack(pc, rows, kdtype(c->dtype)));
     c->conv[id] = pc;
     return 0;
 }
@@ -466,7 +514,7 @@ static int pack_deconv(smk_ctx *c) {
             }
     for (int p = 0; p < 225; ++p)
         for (int co = 0; co < 32; ++co) bias[p * 32 + co] = b->data[co];
-    CHK(upload_packed(pc, rows, bias, c->dtype));
+    CHK(upload_packed(pc, rows, bias, kdtype(c->dtype)));
     c->conv["deconv"] = pc;
     return 0;
 }
@@ -495,7 +543,7 @@ static int pack_stem(smk_ctx *c) {
                 }
         bias[n] = (float)shift[n];
     }
-    CHK(upload_packed(pc, rows, bias, c->dtype));
+    CHK(upload_packed(pc, rows, bias, kdtype(c->dtype)));
     c->conv["stem"] = pc;
     return 0;
 }
@@ -506,7 +554,9 @@ static const int STAGE_BLOCKS[3] = {3, 4, 6};
 
 static int build_weights(smk_ctx *c) {
     const std::string f = "features.features.";
-    CHK(pack_stem(c));
+    const bool x3 = c->dtype == DT_F16X3;              // the trunk of the track path in split operands; mask head + Refine stay plain fp16
+    if (x3) CHK(pack_conv(c, "stem", {bnpart(f + "conv1", f + "bn1")}, 3, 64, 7, false, true));      // (generic 7x7 on [hi | hi | lo] x 8 channels)
+    else CHK(pack_stem(c));
     int inplanes = 64;
     for (int s = 0; s < 3; ++s) {
         const int planes = STAGE_PLANES[s];
@@ -516,17 +566,17 @@ static int build_weights(smk_ctx *c) {
             snprintf(id, sizeof(id), "l%d.%d.", s + 1, b);
             const std::string p = pre, i = id;
             const int cin = b == 0 ? inplanes : planes * 4;
-            CHK(pack_conv(c, i + "c1", {bnpart(p + "conv1", p + "bn1")}, cin, planes, 1, false));
-            CHK(pack_conv(c, i + "c2", {bnpart(p + "conv2", p + "bn2")}, planes, planes, 3, false));
-            CHK(pack_conv(c, i + "c3", {bnpart(p + "conv3", p + "bn3")}, planes, planes * 4, 1, false));
+            CHK(pack_conv(c, i + "c1", {bnpart(p + "conv1", p + "bn1")}, cin, planes, 1, false, x3));
+            CHK(pack_conv(c, i + "c2", {bnpart(p + "conv2", p + "bn2")}, planes, planes, 3, false, x3));
+            CHK(pack_conv(c, i + "c3", {bnpart(p + "conv3", p + "bn3")}, planes, planes * 4, 1, false, x3));
             if (b == 0)
                 CHK(pack_conv(c, i + "ds", {bnpart(p + "downsample.0", p + "downsample.1")}, cin, planes * 4,
-                              s == 0 ? 1 : 3, false));
+                              s == 0 ? 1 : 3, false, x3));
         }
         inplanes = planes * 4;
     }
     CHK(pack_conv(c, "adjust", {bnpart("features.downsample.downsample.0", "features.downsample.downsample.1")},
-                  1024, 256, 1, false));
+                  1024, 256, 1, false, x3));
     std::vector<std::string> br = {"rpn_model.cls.", "rpn_model.loc."};
     if (c->variant != SMK_VARIANT_RPN) br.push_back("mask_model.mask.");
     std::vector<ConvPart> ck, cs, h0;
@@ -535,11 +585,11 @@ static int build_weights(smk_ctx *c) {
         cs.push_back(bnpart(b + "conv_search.0", b + "conv_search.1"));
         h0.push_back(bnpart(b + "head.0", b + "head.1"));
     }
-    CHK(pack_conv(c, "conv_kernel", ck, 256, 256, 3, false));   // N-fused: [cls | loc | mask]
-    CHK(pack_conv(c, "conv_search", cs, 256, 256, 3, false));
-    CHK(pack_conv(c, "head0", h0, 256, 256, 1, true));          // grouped: each branch its own input
-    CHK(pack_conv(c, "cls3", {biaspart("rpn_model.cls.head.3")}, 256, 10, 1, false));
-    CHK(pack_conv(c, "loc3", {biaspart("rpn_model.loc.head.3")}, 256, 20, 1, false));
+    CHK(pack_conv(c, "conv_kernel", ck, 256, 256, 3, false, x3));   // N-fused: [cls | loc | mask]
+    CHK(pack_conv(c, "conv_search", cs, 256, 256, 3, false, x3));
+    CHK(pack_conv(c, "head0", h0, 256, 256, 1, true, x3));          // grouped: each branch its own input
+    CHK(pack_conv(c, "cls3", {biaspart("rpn_model.cls.head.3")}, 256, 10, 1, false, x3));
+    CHK(pack_conv(c, "loc3", {biaspart("rpn_model.loc.head.3")}, 256, 20, 1, false, x3));
     if (c->variant != SMK_VARIANT_RPN)
         CHK(pack_conv(c, "mask3", {biaspart("mask_model.mask.head.3")}, 256, 63 * 63, 1, false));
     if (c->variant == SMK_VARIANT_SHARP) {
@@ -564,7 +614,8 @@ static int build_weights(smk_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 static int alloc_buf(smk_ctx *c, const char *name, size_t elems_per_item) {
     void *p = nullptr;
-    const size_t bytes = elems_per_item * (size_t)c->maxB * esize(c->dtype) + 256;
+    // (DT_F16X3: three channel planes per tensor of the trunk; the Refine buffers get them too -- small, and one rule)
+    const size_t bytes = elems_per_item * (c->dtype == DT_F16X3 ? 3 : 1) * (size_t)c->maxB * esize(c->dtype) + 256;
     HIPCHK(hipMalloc(&p, bytes));
     HIPCHK(hipMemset(p, 0, bytes));
     c->buf[name] = p;
@@ -693,6 +744,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.wgt_frag = pc.w_frag;
     p.wgt_frag_halo = pc.w_frag_halo;
     p.bias = pc.bias;
+    p.oscale = pc.oscale;
     p.pos = o.pos;
     p.B = B;
     p.Hs = in.H; p.Ws = in.W; p.Cs = in.C;
@@ -717,7 +769,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     if (o.groups > 1) {
         p.g_cin_off = pc.Ci;            // branches sit side by side in the channel dimension
         p.g_wgt_off = pc.group_rows;
-        p.g_cout_off = pc.group_rows;
+        p.g_cout_off = pc.group_rows * (pc.x3 ? 3 : 1);      // (split tensors: a branch's three planes side by side)
     }
     if (o.nchw_out) {
         p.out = o.nchw_out;
@@ -732,7 +784,12 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         p.Cos = out->C;
         p.cout_off = o.cout_off;
         p.Nst = rup(p.N, 8);
-        if (o.cout_off + (o.groups - 1) * pc.group_rows + p.Nst > out->C)
+        if (pc.x3) {
+            // split output: whole-tensor planes (stride = a third of the buffer's channels), per-branch planes for a grouped launch
+            p.x3_out = o.groups > 1 ? pc.group_rows : out->C / 3;
+            if (out->C % 3 || o.cout_off + (o.groups - 1) * 3 * pc.group_rows + 2 * p.x3_out + p.Nst > out->C)
+                return fail(SMK_E_ARG, "internal: split conv output channels exceed buffer");
+        } else if (o.cout_off + (o.groups - 1) * pc.group_rows + p.Nst > out->C)
             return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
     }
     p.xcd_mode = g_tune.xcd_mode;
@@ -763,6 +820,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         p.res_Cs = o.res->C;
         p.res_coff = o.res_coff;
         p.res_mode = o.res_mode;
+        if (pc.x3) p.x3_res = o.res->C / 3;
     }
     p.ksplit = 1;
     p.ks_part = c->ks_part;
@@ -899,16 +957,29 @@ static bool seq_layer_from(const ConvParams &p, int dtype, SeqLayer &L, int forc
 // needs every channel of a pixel and no neighbour, so the workgroup that owns 32 whole rows of conv3's output runs it from LDS.
 // Marks the two records of every pair the routine has a shape for; the list itself (tensors, order, barriers behind the pair)
 // stays as recorded.  smk_tune "seq_fuse" 0 leaves the list alone.
+static bool seq_pair_fusable_why(const SeqLayer *L, int i, int *code, int *why);
 static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
+    int why = 0;
+    const bool ok = seq_pair_fusable_why(L, i, code, &why);
+    // SMK_SEQ_DEBUG=1: why is a (1x1 + residual + ReLU, 1x1) pair of records NOT fused?  (stderr, once per list walk)
+    if (!ok && why > 1 && getenv("SMK_SEQ_DEBUG"))
+        fprintf(stderr, "[seq fuse] records %d, %d: not fusable, reason %d (Kpad %d Nst %d -> Nst %d, res %p relu %d, b.relu %d b.Ho %d Hs %d)\n", i, i + 1, why,
+                (int)L[i].Kpad, (int)L[i].Nst, (int)L[i + 1].Nst, L[i].res, (int)L[i].relu, (int)L[i + 1].relu, (int)L[i + 1].Ho, (int)L[i + 1].Hs);
+    return ok;
+}
+static bool seq_pair_fusable_why(const SeqLayer *L, int i, int *code, int *why) {
     const SeqLayer &a = L[i], &b = L[i + 1];
     auto plain1x1 = [](const SeqLayer &l) {
         return l.kh == 1 && l.kw == 1 && l.stride == 1 && l.stride_x == 1 && l.pad == 0 && l.org_y == 0 && l.org_x == 0 &&
                l.Hl == l.Hs && l.Wl == l.Ws && l.Ho == l.Hs && l.Wo == l.Ws && l.Ci == l.Kpad;
     };
-    if (!plain1x1(a) || !plain1x1(b) || !a.sync) return false;
-    if (!a.res || a.res_mode != RES_PRE_RELU || !a.relu || b.res || b.res_mode != RES_NONE) return false;
-    if (b.in != a.out || b.cin_off != a.cout_off || b.Cs != a.Cos || b.Ci != a.Nst || b.Hs != a.Ho || b.Ws != a.Wo) return false;
-    if (b.out == a.out || b.out == a.res || b.out == a.in) return false;
+    if (!plain1x1(a) || !a.sync) { *why = 1; return false; }
+    if (!plain1x1(b)) { *why = 2; return false; }
+    if (!a.res || a.res_mode != RES_PRE_RELU || !a.relu) { *why = 1; return false; }
+    if (b.res || b.res_mode != RES_NONE) { *why = 3; return false; }
+    if (b.in != a.out) { *why = 1; return false; }
+    if (b.cin_off != a.cout_off || b.Cs != a.Cos || b.Ci != a.Nst || b.Hs != a.Ho || b.Ws != a.Wo) { *why = 4; return false; }
+    if (b.out == a.out || b.out == a.res || b.out == a.in) { *why = 5; return false; }
     // The routine fetches the residual BEFORE it waits at its hoist point.  The barrier still pending there is the one behind
     // the LAST layer before i that carries one (`pend`; layer i - 1 when it has sync = 1, an earlier one when smk_op_conv_seq's
     // caller chained independent members with sync = 0).  Whoever wrote the residual inside this list must be separated from
@@ -922,18 +993,18 @@ static bool seq_pair_fusable(const SeqLayer *L, int i, int *code) {
         if (L[j].out == a.res) {
             bool passed = false;
             for (int k = j; k < pend; ++k) passed = passed || has_bar(k);
-            if (!passed) return false;
+            if (!passed) { *why = 6; return false; }
             break;
         }
     // conv3's own input must be behind the pending barrier too (the hoist point is the only wait in front of its loads)
     for (int j = i - 1; j >= 0; --j)
         if (L[j].out == a.in) {
-            if (j > pend) return false;
+            if (j > pend) { *why = 7; return false; }
             break;
         }
     if (a.Kpad == 256 && a.Nst == 1024 && b.Nst == 256) *code = SEQ_CFG_C3C1_L3;
     else if (a.Kpad == 128 && a.Nst == 512 && b.Nst == 128) *code = SEQ_CFG_C3C1_L2;
-    else return false;
+    else { *why = 8; return false; }
     return true;
 }
 static int g_seq_fused_last = 0;          // pairs fused in the list that was launched last (smk_tune_get "seq_fused_last", a diagnostic)
@@ -1341,18 +1412,18 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
     if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", id);
     ConvParams p;
     CHK(conv_params(c, it->second, in, out, B, o, p));
-    const TileChoice t = tile_from_code(o.tile_code, p, c->dtype);
+    const TileChoice t = tile_from_code(o.tile_code, p, kdtype(c->dtype));
     const int ng = p.groups > 0 ? p.groups : 1;
     // algorithmic work: 2*M*N*K_real flops; bytes = activations read once + weights + output written once
     const double kreal = it->second.alg_k ? (double)it->second.alg_k : (double)p.kh * p.kw * p.Ci;
     const double flop = 2.0 * p.M * (double)p.N * kreal * ng;
-    const size_t es = esize(c->dtype);
+    const size_t es = esize(kdtype(c->dtype));
     const double in_bytes = (double)B * (p.ups ? p.Hs * p.Ws : (double)p.Hl * p.Wl) * p.Ci * es * ng;
     const double out_bytes = (double)p.M * p.N * ng * (p.out_mode == OUT_NCHW_F32 ? 4 : es);
     const double bytes = in_bytes + out_bytes + (double)p.N * kreal * es * ng + (p.res ? (double)p.M * p.N * es : 0.0);
     if (c->seq_on) {
         SeqLayer L;
-        if (!o.algo_naive && !o.halo && !o.wreg && !o.tile_code && seq_layer_from(p, c->dtype, L)) {
+        if (!o.algo_naive && !o.halo && !o.wreg && !o.tile_code && seq_layer_from(p, kdtype(c->dtype), L)) {
             c->seq_rec.push_back(L);
             c->seq_wstd.push_back(p.wgt_frag);
             c->seq_ids.push_back(id);
@@ -1363,27 +1434,27 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
         CHK(seq_flush(c, B, s));               // not eligible: keep program order
     }
     char kn[64];
-    snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
+    snprintf(kn, sizeof(kn), "conv_igemm<%s,%dx%dx%d,s%d,%s>", dtname(kdtype(c->dtype)), t.bm, t.bn, t.kt, t.stages,
              p.out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc");
     int rc = 1;
-    int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, c->dtype);
-    if (bm && !o.halo && conv_ksplit(p, c->dtype, t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
+    int bm = o.algo_naive ? 0 : halo_choice(it->second, p, o, kdtype(c->dtype));
+    if (bm && !o.halo && conv_ksplit(p, kdtype(c->dtype), t) > 1) bm = 0;       // under-filled: split-K on the generic kernel wins
     // (policy 1 decides between the register-fed and the patch-sharing kernel itself; the round-2 table only covered the
     //  layers the patch-sharing kernel does not take)
-    if (pp_choice(p, o, c->dtype)) {
+    if (pp_choice(p, o, kdtype(c->dtype))) {
         ProfScope ps(c, s, id, "conv_pp<f16,256x256>", flop, bytes);
         rc = launch_conv_pp(p, s);
         if (rc == 1) ps.cancel();
         else bm = 0;
     }
-    const int wr = (rc != 1 || o.halo || (bm && !o.wreg && g_tune.wreg < 2 && g_tune.wreg_policy == 0)) ? 0 : wreg_choice(p, o, c->dtype);
+    const int wr = (rc != 1 || o.halo || (bm && !o.wreg && g_tune.wreg < 2 && g_tune.wreg_policy == 0)) ? 0 : wreg_choice(p, o, kdtype(c->dtype));
     if (wr) {
         // weights straight into registers, activations through LDS
         ConvBatch cb;
         cb.n = 1;
         cb.p[0] = p;
         char kw_[64];
-        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(c->dtype), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages());
+        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages());
         ProfScope ps(c, s, id, kw_, flop, bytes);
         rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
         if (rc == 1) ps.cancel();
@@ -1394,14 +1465,14 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
         ConvParams ph = p;
         ph.wgt = it->second.w_halo;
         char kh_[64];
-        snprintf(kh_, sizeof(kh_), "conv3x3_halo<%s,%dx128>", dtname(c->dtype), bm);
+        snprintf(kh_, sizeof(kh_), "conv3x3_halo<%s,%dx128>", dtname(kdtype(c->dtype)), bm);
         ProfScope ps(c, s, id, kh_, flop, bytes);
-        rc = launch_conv_halo(ph, c->dtype, bm, s);
+        rc = launch_conv_halo(ph, kdtype(c->dtype), bm, s);
         if (rc == 1) ps.cancel();
     }
     if (rc == 1) {
         ProfScope ps(c, s, id, o.algo_naive ? "conv_naive" : kn, flop, bytes);
-        rc = o.algo_naive ? launch_conv_naive(p, c->dtype, s) : launch_conv_mfma(p, c->dtype, t, s);
+        rc = o.algo_naive ? launch_conv_naive(p, kdtype(c->dtype), s) : launch_conv_mfma(p, kdtype(c->dtype), t, s);
     }
     if (rc) return fail(SMK_E_HIP, "launch of conv %s failed: %s", id, hipGetErrorString(hipGetLastError()));
     return 0;
@@ -1431,7 +1502,7 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
         auto it = c->conv.find(jobs[i].id);
         if (it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv %s not packed", jobs[i].id);
         CHK(conv_params(c, it->second, *jobs[i].in, jobs[i].out, B, jobs[i].o, cb.p[i]));
-        const int bm = halo_choice(it->second, cb.p[i], jobs[i].o, c->dtype);
+        const int bm = halo_choice(it->second, cb.p[i], jobs[i].o, kdtype(c->dtype));
         if (bm) ++n_halo;
         if (bm == 64 || (bm == 0 && cb.p[i].kh == 3)) split_for_halo = false;
     }
@@ -1447,7 +1518,7 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
     double mflop = 0.0, mbytes = 0.0;
     std::string mid;
     if (c->prof) {
-        const size_t es = esize(c->dtype);
+        const size_t es = esize(kdtype(c->dtype));
         for (int i = 0; i < cb.n; ++i) {
             const ConvParams &q = cb.p[i];
             const PackedConv &pc = c->conv.find(jobs[i].id)->second;
@@ -1461,12 +1532,12 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
         }
     }
     {
-        int wr = wreg_choice(cb.p[lead], jobs[lead].o, c->dtype);
+        int wr = wreg_choice(cb.p[lead], jobs[lead].o, kdtype(c->dtype));
         for (int i = 0; i < cb.n && wr; ++i)
-            if (!wreg_choice(cb.p[i], jobs[i].o, c->dtype)) wr = 0;
+            if (!wreg_choice(cb.p[i], jobs[i].o, kdtype(c->dtype))) wr = 0;
         if (wr) {
             char kw_[64];
-            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(c->dtype), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), cb.n);
+            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), cb.n);
             ProfScope ps(c, s, mid.c_str(), kw_, mflop, mbytes);
             const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
             if (rc == 0) return 0;
@@ -1474,12 +1545,12 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
             if (rc != 1) return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
         }
     }
-    const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], c->dtype);
+    const TileChoice t = tile_from_code(jobs[lead].o.tile_code, cb.p[lead], kdtype(c->dtype));
     char km_[72];
-    snprintf(km_, sizeof(km_), "conv_igemm<%s,%dx%dx%d,s%d,%s,merged%d>", dtname(c->dtype), t.bm, t.bn, t.kt, t.stages,
+    snprintf(km_, sizeof(km_), "conv_igemm<%s,%dx%dx%d,s%d,%s,merged%d>", dtname(kdtype(c->dtype)), t.bm, t.bn, t.kt, t.stages,
              cb.p[lead].out_mode == OUT_NCHW_F32 ? "nchw" : "nhwc", cb.n);
     ProfScope psm(c, s, mid.c_str(), km_, mflop, mbytes);
-    if (launch_conv_mfma_batch(cb, c->dtype, t, s))
+    if (launch_conv_mfma_batch(cb, kdtype(c->dtype), t, s))
         return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
     return 0;
 }
@@ -1529,12 +1600,19 @@ static int run_conv_pair(smk_ctx *c, const char *id3, const Act &in3, const Act 
 // phase: PH_FRONT = stem + maxpool + layer1 (p0, p1), PH_BACK = layer2 .. adjust from the kept p1; both = the whole backbone.
 // The pipelined frame step (smk_set_pipeline) runs the two halves as separate graphs.
 enum { PH_FRONT = 1, PH_BACK = 2, PH_ALL = 3 };
-static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s, int phase = PH_ALL) {
+// search_nb / search_nbt > 0 (the search branch's callers): conv_search x search_nb (models/rpn.py:50-54, N-fused) is issued HERE, behind adjust
+// and in front of the sequence's flush, so that it becomes the persistent launch's last record (round 6, smk_tune "seq_search"): no kernel
+// boundary, no cold start, the weights behind the team's own L2 -- the register-fed 128 x 256 tiles run at 0.58 us per K tile inside the
+// sequence where the stand-alone launch needs 0.9.  *search_done tells the caller that conv_search has been issued (recorded or launched).
+static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s, int phase = PH_ALL, int search_nb = 0, int search_nbt = 0,
+                        bool *search_done = nullptr) {
+    // DT_F16X3: the trunk's tensors are [hi | hi | lo] planes -- three times the channels (smk_kernels.h)
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
     const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
     const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
     const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
-    Act p0 = act(c, "p0", s0, s0, 64);
-    Act x1 = act(c, "x1", s1, s1, 64);
+    Act p0 = act(c, "p0", s0, s0, X(64));
+    Act x1 = act(c, "x1", s1, s1, X(64));
     auto stem_it = c->conv.find("stem");
     if (stem_it == c->conv.end()) return fail(SMK_E_STATE, "internal: conv stem not packed");
     if (!(phase & PH_FRONT)) {
@@ -1545,12 +1623,28 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
         ProfScope ps(c, s, "stem_pool", "stem_pool", 2.0 * B * s0 * s0 * 64.0 * 147.0,
                      (double)B * (3.0 * S * S * 4 + ((double)s0 * s0 + (double)s1 * s1) * 64 * 2));
         if (launch_stem_pool(sp_, s)) return fail(SMK_E_HIP, "stem_pool launch failed: %s", hipGetErrorString(hipGetLastError()));
+    } else if (c->dtype == DT_F16X3) {
+        // split operands: frame -> [hi | hi | lo] x 8 channels, the 7x7 stem as a generic convolution on them, the pool on hi + lo
+        Act xin = act(c, "xin", S, S, 24);
+        CvtInParams ci{x, xin.p, B, 3, S, S, 8, 0, 1};
+        {
+            ProfScope ps(c, s, "cvt_in", "cvt_in_x3", 0.0, (double)B * S * S * (3 * 4 + 24 * 2));
+            if (launch_cvt_in_x3(ci, s)) return fail(SMK_E_HIP, "cvt_in_x3 launch failed");
+        }
+        ConvOpt o;
+        o.stride = 2; o.relu = 1;
+        CHK(run_conv(c, "stem", xin, &p0, B, o, s));
+        PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1, 1};
+        {
+            ProfScope ps(c, s, "maxpool", "maxpool_x3", 0.0, (double)B * 3 * 64 * 2 * (s0 * s0 + s1 * s1));
+            if (launch_maxpool_x3(pp, s)) return fail(SMK_E_HIP, "maxpool_x3 launch failed");
+        }
     } else {
         Act xin = act(c, "xin", S, (S + 1) / 2, 8);            // pixel-pair layout (see pack_stem)
         CvtInParams ci{x, xin.p, B, 3, S, S, 8, 1};
         {
             ProfScope ps(c, s, "cvt_in", "cvt_in", 0.0, (double)B * S * S * (3 * 4 + 8 * esize(c->dtype)));
-            if (launch_cvt_in(ci, c->dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+            if (launch_cvt_in(ci, kdtype(c->dtype), s)) return fail(SMK_E_HIP, "cvt_in launch failed");
         }
         ConvOpt o;
         o.stride = 2; o.stride_x = 1; o.relu = 1;
@@ -1558,7 +1652,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
         PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1};
         {
             ProfScope ps(c, s, "maxpool", "maxpool", 0.0, (double)B * 64 * esize(c->dtype) * (s0 * s0 + s1 * s1));
-            if (launch_maxpool(pp, c->dtype, s)) return fail(SMK_E_HIP, "maxpool launch failed");
+            if (launch_maxpool(pp, kdtype(c->dtype), s)) return fail(SMK_E_HIP, "maxpool launch failed");
         }
     }
 
@@ -1576,7 +1670,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
     for (int st = 0; st < 3; ++st) {
         // layer1 stays on the per-launch kernels: short K and 63 tiles of 64 rows per image (two rounds for 32 workgroups)
         // made it 140 us inside the sequence against 96 us as launches (SMK_SEQ_CLK, profiles/r02_seq_ab.txt)
-        if (st == 0 && !(phase & PH_FRONT)) { cur = act(c, "p1", s1, s1, 256); continue; }
+        if (st == 0 && !(phase & PH_FRONT)) { cur = act(c, "p1", s1, s1, X(256)); continue; }
         if (st == 1 && !(phase & PH_BACK)) { c->last_B = B; c->last_S = S; return 0; }
         if (seq_ok && st == g_tune.seq_first_stage) c->seq_on = true;
         const int planes = STAGE_PLANES[st];
@@ -1597,7 +1691,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
                     return fail(SMK_E_STATE, "internal: layer1 block %d not packed for l1_block_kernel", b);
                 const bool last1 = b == STAGE_BLOCKS[0] - 1;
                 const char *on = last1 ? "p1" : ((b & 1) ? "b" : "a");
-                Act out1 = act(c, on, sp, sp, 256);
+                Act out1 = act(c, on, sp, sp, X(256));
                 L1BlockParams lp;
                 memset(&lp, 0, sizeof(lp));
                 lp.x = cur.p; lp.y = out1.p;
@@ -1628,8 +1722,8 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
             // one layout per buffer (see build_arena): stage-private names, and layer2.0's pre-stride conv1 output on its own
             static const char *T1N[3] = {"t1", "t1_2", "t1_3"}, *T2N[3] = {"t2", "t2_2", "t2_3"}, *RN[3] = {"r", "r_2", "r_3"},
                               *AN[3] = {"a", "a_2", "a_3"}, *BN[3] = {"b", "b_2", "b_3"};
-            Act t1 = act(c, stride == 2 ? "t1_s" : T1N[st], sp, sp, planes);
-            Act t2 = act(c, T2N[st], so, so, planes);
+            Act t1 = act(c, stride == 2 ? "t1_s" : T1N[st], sp, sp, X(planes));
+            Act t2 = act(c, T2N[st], so, so, X(planes));
             ConvOpt o1; o1.relu = 1;
             ConvOpt o2; o2.relu = 1; o2.stride = stride; o2.pad = pad2; o2.dil = dil;
             Act res = cur;
@@ -1637,7 +1731,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
             const std::string id_ds = id + "ds", id_c1 = id + "c1";
             if (b == 0) {
                 // the shortcut conv only depends on the block input: it shares a launch with conv1
-                Act r = act(c, RN[st], so, so, planes * 4);
+                Act r = act(c, RN[st], so, so, X(planes * 4));
                 ConvOpt od;
                 if (st == 0) { od.stride = 1; od.pad = 0; }          // 1x1
                 else if (st == 1) { od.stride = 2; od.pad = 0; }     // 3x3 s2 p0
@@ -1660,7 +1754,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
             const bool last = b == STAGE_BLOCKS[st] - 1;
             const char *oname = last ? (st == 0 ? "p1" : st == 1 ? "p2" : AN[2]) : ((b & 1) ? BN[st] : AN[st]);
             if (last && st == 2 && cur.p == c->buf.at(AN[2])) oname = BN[2];
-            Act out = act(c, oname, so, so, planes * 4);
+            Act out = act(c, oname, so, so, X(planes * 4));
             if (last && st == 2) c->p3_buf = oname;
             ConvOpt o3; o3.relu = 1; o3.res = &res; o3.res_mode = RES_PRE_RELU;
             // outside the persistent sequence: conv3 and the NEXT 1x1 convolution (the following block's conv1, or adjust behind
@@ -1670,13 +1764,13 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
                 if (!last) {
                     char idn[32];
                     snprintf(idn, sizeof(idn), "l%d.%d.c1", st + 1, b + 1);
-                    Act t1n = act(c, T1N[st], so, so, planes);
+                    Act t1n = act(c, T1N[st], so, so, X(planes));
                     ConvOpt o1n; o1n.relu = 1;
                     paired = run_conv_pair(c, (id + "c3").c_str(), t2, out, o3, idn, t1n, o1n, B, s);
                     if (paired < 0) return paired;
                     if (paired == 0) c1_done = true;
                 } else if (st == 2 && so >= 20) {
-                    Act se = act(c, "search", so, so, 256);
+                    Act se = act(c, "search", so, so, X(256));
                     ConvOpt oa0;
                     paired = run_conv_pair(c, (id + "c3").c_str(), t2, out, o3, "adjust", se, oa0, B, s);
                     if (paired < 0) return paired;
@@ -1691,12 +1785,19 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
     // adjust: 1x1 1024->256 + BN, no ReLU; template (15 < 20): centre crop [4:-4] (custom.py:21-24)
     ConvOpt oa;
     if (sp < 20) {
-        Act zf = act(c, "zf", sp - 8, sp - 8, 256);
+        Act zf = act(c, "zf", sp - 8, sp - 8, X(256));
         oa.win = true; oa.Hl = oa.Wl = sp - 8; oa.org_y = oa.org_x = 4;
         CHK(run_conv(c, "adjust", cur, &zf, B, oa, s));
     } else if (!adjust_done) {
-        Act se = act(c, "search", sp, sp, 256);
+        Act se = act(c, "search", sp, sp, X(256));
         CHK(run_conv(c, "adjust", cur, &se, B, oa, s));
+    }
+    if (c->seq_on && search_nb > 0 && sp >= 20 && g_tune.seq_search && c->seq_rec.size() < (size_t)SEQ_MAX) {
+        Act se = act(c, "search", sp, sp, X(256));
+        Act xs = act(c, "xs", sp - 2, sp - 2, X(256 * search_nbt));
+        ConvOpt o; o.relu = 1; o.n_override = 256 * search_nb;
+        CHK(run_conv(c, "conv_search", se, &xs, B, o, s));         // (not eligible for the sequence: flushed + launched, still done)
+        if (search_done) *search_done = true;
     }
     if (c->seq_on) CHK(seq_flush(c, B, s));
     c->last_B = B; c->last_S = S;
@@ -1704,10 +1805,11 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
 }
 
 static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
     CHK(run_backbone(c, z, B, 127, s));
     const int nb = nbranch(c);
-    Act zf = act(c, "zf", 7, 7, 256);
-    Act zk = act(c, "zk", 5, 5, 256 * nb);
+    Act zf = act(c, "zf", 7, 7, X(256));
+    Act zk = act(c, "zk", 5, 5, X(256 * nb));
     ConvOpt o; o.relu = 1;                       // conv_kernel: 3x3 p0 + BN + ReLU (rpn.py:45-49), all branches fused
     CHK(run_conv(c, "conv_kernel", zf, &zk, B, o, s));
     return 0;
@@ -1718,13 +1820,16 @@ static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
 // beside the small decode / Refine launches instead of in front of them
 static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
                      hipStream_t s, bool defer_mask_join = false, int phase = PH_ALL) {
-    CHK(run_backbone(c, x, B, 255, s, phase));
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    const bool x3 = c->dtype == DT_F16X3;
     const int nbt = nbranch(c);                                   // branches laid out in the buffers
     const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
-    Act se = act(c, "search", 31, 31, 256);
-    Act xs = act(c, "xs", 29, 29, 256 * nbt);
+    bool search_done = false;
+    CHK(run_backbone(c, x, B, 255, s, phase, nb, nbt, &search_done));
+    Act se = act(c, "search", 31, 31, X(256));
+    Act xs = act(c, "xs", 29, 29, X(256 * nbt));
     ConvOpt o; o.relu = 1; o.n_override = 256 * nb;               // conv_search x nb as one N-fused GEMM
-    CHK(run_conv(c, "conv_search", se, &xs, B, o, s));
+    if (!search_done) CHK(run_conv(c, "conv_search", se, &xs, B, o, s));
     if (c->pipe_gate_late) {
         // pipelined step without the persistent sequence: nothing up to here writes what the previous frame's tail reads (p0 / p1 / p2
         // exist twice), so the gate sits HERE -- the tail has the whole backbone of this frame to finish beside -- and the heads below
@@ -1732,8 +1837,8 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
         if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, s)) return fail(SMK_E_HIP, "pipe_gate launch failed");
         c->cap_has_seq = true;
     }
-    Act corr = act(c, "corr", 25, 25, 256 * nbt);
-    Act h0 = act(c, "head0", 25, 25, 256 * nbt);
+    Act corr = act(c, "corr", 25, 25, X(256 * nbt));
+    Act h0 = act(c, "head0", 25, 25, X(256 * nbt));
     const bool par = parallel_ok(c);
     const bool want_mask = (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD);
     hipStream_t s_loc = par ? c->side[0] : s, s_cls = (par && want_mask) ? c->side[1] : s;
@@ -1766,15 +1871,16 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     {
         // algorithmic bytes per branch-item: read 256*(29*29 + 5*5), write 256*25*25 elements
         const double xb = (double)B * nb * 256.0 * (29 * 29 + 25 + 625) * esize(c->dtype);
-        ProfScope ps(c, s, "dw_xcorr", "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, xb);
-        if (launch_xcorr(xp, c->dtype, s)) return fail(SMK_E_HIP, "xcorr launch failed");
+        ProfScope ps(c, s, "dw_xcorr", x3 ? "dw_xcorr_x3" : "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, x3 ? 3.0 * xb : xb);
+        // (split operands: xs / zk in whole-tensor planes, corr in per-branch planes -- head.0 is a grouped convolution)
+        if (x3 ? launch_xcorr_x3(xp, s) : launch_xcorr(xp, kdtype(c->dtype), s)) return fail(SMK_E_HIP, "xcorr launch failed");
     }
     ConvOpt oh; oh.relu = 1; oh.groups = nb;                      // head.0 1x1 + BN + ReLU per branch
     CHK(run_conv(c, "head0", corr, &h0, B, oh, s));
     // the three head.3 convs are independent: cls / loc / mask side by side
     if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
-    ConvOpt ol; ol.nchw_out = loc; ol.cin_off = 256;
+    ConvOpt ol; ol.nchw_out = loc; ol.cin_off = x3 ? 768 : 256;
     if (par) {
         CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
         CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
@@ -1783,7 +1889,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     }
     }
     if (want_mask) {
-        ConvOpt om; om.nchw_out = mask; om.cin_off = 512;
+        ConvOpt om; om.nchw_out = mask; om.cin_off = x3 ? 2 * 768 : 512;      // (x3: plain fp16 pack on the hi plane of the mask branch)
         if (c->defer_mask_req && !par) {
             // handed to seq_refine: it runs inside the chain launch, beside the (B-workgroup) Refine chain
             auto it = c->conv.find("mask3");
@@ -1814,8 +1920,10 @@ static bool refine_splittable(const smk_ctx *c, int B) {
 }
 static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0) {
     const int *pos = c->pos_dev;
-    Act corr = act(c, "corr", 25, 25, 256 * 3);
-    Act p0 = act(c, "p0", 125, 125, 64), p1 = act(c, "p1", 63, 63, 256), p2 = act(c, "p2", 31, 31, 512);
+    // (DT_F16X3: Refine runs in plain fp16 on the hi planes of the kept trunk tensors -- channel stride 3 C, first C channels)
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    Act corr = act(c, "corr", 25, 25, X(256 * 3));
+    Act p0 = act(c, "p0", 125, 125, X(64)), p1 = act(c, "p1", 63, 63, X(256)), p2 = act(c, "p2", 31, 31, X(512));
     // The three window convs v2.0 / v1.0 / v0.0 (the heavy part of Refine) depend only on the
     // kept backbone features and pos: they run on a side stream beside deconv -> h2 -> ...
     ConvOpt r3; r3.pad = 1; r3.relu = 1;
@@ -1840,7 +1948,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0
     }
     // deconv(corr_feature[:, :, y, x]) -> [15,15,32]            (:145,:149)
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
-    ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = 512;
+    ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = c->dtype == DT_F16X3 ? 2 * 768 : 512;
     Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
     const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
     if (merged && part != 2) {
@@ -2105,7 +2213,8 @@ static int seq_grid_for(int ncu) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
-int smk_version(void) { return (1 << 16) | 5; }   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
+int smk_version(void) { return (1 << 16) | 6; }   // 1.6: SMK_DTYPE_F16X3 (split-operand fp16 contexts)
+//   // 1.2: smk_decode / smk_step take float64 target_wh and write a float64 box; 1.3: smk_op_conv_seq,
                                                   // sequence failures reported at the next entry point
 
 const char *smk_last_error(void) { return g_err.c_str(); }
@@ -2113,7 +2222,7 @@ const char *smk_last_error(void) { return g_err.c_str(); }
 int smk_create(smk_ctx **out, int device, int dtype, int variant, int max_batch) {
     if (!out) return fail(SMK_E_ARG, "smk_create: out is NULL");
     *out = nullptr;
-    if (dtype != SMK_DTYPE_F32 && dtype != SMK_DTYPE_F16) return fail(SMK_E_ARG, "smk_create: bad dtype %d", dtype);
+    if (dtype != SMK_DTYPE_F32 && dtype != SMK_DTYPE_F16 && dtype != SMK_DTYPE_F16X3) return fail(SMK_E_ARG, "smk_create: bad dtype %d", dtype);
     if (variant < SMK_VARIANT_RPN || variant > SMK_VARIANT_SHARP) return fail(SMK_E_ARG, "smk_create: bad variant %d", variant);
     if (max_batch < 1 || max_batch > 1024) return fail(SMK_E_ARG, "smk_create: max_batch %d out of range", max_batch);
     int ndev = 0;
@@ -2158,7 +2267,7 @@ int smk_destroy(smk_ctx *c) {
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (auto &kv : c->buf)
         if (!c->buf_alias.count(kv.first)) hipFree(kv.second);
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); hipFree(kv.second.oscale); }
     if (c->pos_dev) hipFree(c->pos_dev);
     if (c->dec_scratch) hipFree(c->dec_scratch);
     if (c->ks_part) hipFree(c->ks_part);
@@ -2205,7 +2314,7 @@ int smk_finalize_weights(smk_ctx *c) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); hipFree(kv.second.oscale); }
     c->conv.clear();
     int rc = build_weights(c);
     if (rc) return rc;
@@ -2244,6 +2353,7 @@ int smk_packed_size(smk_ctx *c, uint64_t *bytes) {
 int smk_export_packed(smk_ctx *c, void *host_buf, uint64_t capacity) {
     if (!c || !host_buf) return fail(SMK_E_ARG, "smk_export_packed: null argument");
     if (!c->finalized) return fail(SMK_E_STATE, "smk_export_packed: weights not finalized");
+    if (c->dtype == DT_F16X3) return fail(SMK_E_ARG, "smk_export_packed: split-operand contexts re-pack from the state dict (no blob format for the tripled K)");
     const size_t need = packed_bytes(c);
     if (capacity < need) return fail(SMK_E_ARG, "smk_export_packed: buffer too small (%zu needed)", need);
     HIPCHK(hipSetDevice(c->device));
@@ -2274,6 +2384,7 @@ int smk_export_packed(smk_ctx *c, void *host_buf, uint64_t capacity) {
 int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     if (!c || !host_buf) return fail(SMK_E_ARG, "smk_import_packed: null argument");
     if (bytes < sizeof(PackHeader)) return fail(SMK_E_WEIGHT, "smk_import_packed: truncated blob");
+    if (c->dtype == DT_F16X3) return fail(SMK_E_ARG, "smk_import_packed: split-operand contexts re-pack from the state dict");
     const unsigned char *p = (const unsigned char *)host_buf, *end = p + bytes;
     PackHeader h;
     memcpy(&h, p, sizeof(h)); p += sizeof(h);
@@ -2288,7 +2399,7 @@ int smk_import_packed(smk_ctx *c, const void *host_buf, uint64_t bytes) {
     for (auto &kv : c->graphs) hipGraphExecDestroy(kv.second);
     c->graphs.clear();
     c->graph_used.clear();
-    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); }
+    for (auto &kv : c->conv) { hipFree(kv.second.w); hipFree(kv.second.w_halo); hipFree(kv.second.w_frag); hipFree(kv.second.w_frag16); hipFree(kv.second.w_frag_halo); hipFree(kv.second.bias); hipFree(kv.second.oscale); }
     c->conv.clear();
     c->finalized = false;
     for (int i = 0; i < h.n_conv; ++i) {
@@ -2524,6 +2635,7 @@ int smk_tune(const char *key, int value) {
 #endif
     }
     else if (!strcmp(key, "seq_yres")) g_tune.seq_yres = value != 0;
+    else if (!strcmp(key, "seq_search")) g_tune.seq_search = value != 0;
     else if (!strcmp(key, "pp")) { if (value < 0 || value > 2) return fail(SMK_E_ARG, "pp 0..2"); g_tune.pp = value; }
     else if (!strcmp(key, "pipe_late")) g_tune.pipe_late = value != 0;
     else if (!strcmp(key, "nt_store")) g_tune.nt_store = value != 0;
@@ -2553,7 +2665,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -3054,6 +3166,17 @@ int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int
             if (c->last_B < 1) return fail(SMK_E_STATE, "smk_debug_read: nothing has run yet");
             CHK(pipe_join(c, (hipStream_t)stream, true));
             c->parity_now = c->last_parity;            // p0 / p1: the copy the last tracked frame wrote
+            if (c->dtype == DT_F16X3) {
+                // split tensors: value = hi + lo.  Whole-tensor planes, except corr / head0 (per-branch planes: 256 g + cc -> 768 g + cc)
+                const bool per_branch = !strcmp(e.n, "corr") || !strcmp(e.n, "head0");
+                const int ng = per_branch ? e.cn / 256 : 1, cg = e.cn / ng;
+                for (int g = 0; g < ng; ++g) {
+                    CvtOutParams p{act(c, e.b, e.h, e.w, 3 * e.cs).p, dst, c->last_B, cg, e.h, e.w, 3 * e.cs, g * 768, per_branch ? 256 : e.cs};
+                    if (ng > 1) return fail(SMK_E_ARG, "smk_debug_read: %s of a split-operand context is read per branch: not implemented", e.n);
+                    if (launch_cvt_out_x3(p, stream)) return fail(SMK_E_HIP, "cvt_out launch failed");
+                }
+                return 0;
+            }
             CvtOutParams p{act(c, e.b, e.h, e.w, e.cs).p, dst, c->last_B, e.cn, e.h, e.w, e.cs, 0};
             if (launch_cvt_out(p, c->dtype, stream)) return fail(SMK_E_HIP, "cvt_out launch failed");
             return 0;
@@ -3128,21 +3251,41 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
                      const float *b_host, const float *res_dev, const int32_t *pos_host, float *y_dev,
                      void *stream) {
     if (!g || !x_dev || !w_host || !y_dev) return fail(SMK_E_ARG, "smk_op_conv2d_ex: null argument");
-    if (dtype != DT_F32 && dtype != DT_F16) return fail(SMK_E_ARG, "bad dtype");
+    if (dtype != DT_F32 && dtype != DT_F16 && dtype != DT_F16X3) return fail(SMK_E_ARG, "bad dtype");
+    // DT_F16X3 (unit parity of the split-operand convolution): x, res -> [hi | hi | lo] planes, the pack tripled per tap, conv_igemm_kernel's
+    // (or wreg_tile's) splitting epilogue, the output read back as hi + lo.  NHWC epilogue only, whole channel range.
+    const bool x3 = dtype == DT_F16X3;
+    if (x3 && (((algo & 0xff) != 0 && (algo & 0xff) != 5) || g->cin_off || g->cin_len))
+        return fail(SMK_E_ARG, "smk_op_conv2d_ex: split-operand convolutions: algo 0 (conv_igemm_kernel) or 5 (conv_wreg_kernel), no channel slice");
+    const int ctx_dtype = dtype;
+    dtype = kdtype(dtype);
     hipStream_t s = (hipStream_t)stream;
     PackedConv pc; Act in; ConvOpt o; int Ho, Wo;
     CHK(fill_geom(g, pc, in, o, Ho, Wo));
     std::vector<float> rows, bias;
     pack_host(g, pc, w_host, b_host, rows, bias);
+    if (x3) {
+        const int Ci0 = pc.Ci, K1 = pc.Kpad;
+        pc.x3 = true;
+        pc.alg_k = g->k * g->k * Ci0;
+        pc.Ci = 3 * Ci0;
+        pc.K = g->k * g->k * pc.Ci;
+        pc.Kpad = rup(pc.K, KPAD_ALIGN);
+        std::vector<float> osc;
+        split_rows_x3(rows, pc.rows, K1, pc.Kpad, g->k * g->k, Ci0, osc);
+        CHK(upload_oscale(pc, osc));
+        in.C *= 3;
+    }
     CHK(upload_packed(pc, rows, bias, dtype));
     TmpBufs tmp;
     tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);
     if (pc.w_frag) tmp.v.push_back(pc.w_frag);
     if (pc.w_frag16) tmp.v.push_back(pc.w_frag16);
+    if (pc.oscale) tmp.v.push_back(pc.oscale);
     const size_t es = esize(dtype);
     CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
-    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, in.C, 0};
-    if (launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, x3 ? in.C / 3 : in.C, 0, x3 ? 1 : 0};
+    if (x3 ? launch_cvt_in_x3(ci, s) : launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     int *pos_dev = nullptr;
     if (pos_host) {
         CHK(tmp.alloc((void **)&pos_dev, sizeof(int) * 2 * g->B));
@@ -3161,17 +3304,17 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         tmp.v.push_back(pc.w_halo);
     }
     Act out, res;
-    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8);
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8) * (x3 ? 3 : 1);
     if (res_dev && g->res_mode) {
         if (nchw) return fail(SMK_E_ARG, "residual is not supported with the NCHW epilogue");
         res = out;
         CHK(tmp.alloc(&res.p, (size_t)g->B * Ho * Wo * out.C * es));
-        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, out.C, 0};
-        if (launch_cvt_in(cr, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
+        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, x3 ? out.C / 3 : out.C, 0, x3 ? 1 : 0};
+        if (x3 ? launch_cvt_in_x3(cr, s) : launch_cvt_in(cr, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
         o.res = &res; o.res_mode = g->res_mode;
     }
     smk_ctx fake;
-    fake.dtype = dtype;
+    fake.dtype = ctx_dtype;
     HIPCHK(hipGetDevice(&fake.device));
     CHK(op_ks_scratch(fake));
     ConvParams p;
@@ -3205,8 +3348,8 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     }
     if (rc) return fail(SMK_E_HIP, "conv launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (!nchw) {
-        CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0};
-        if (launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
+        CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0, x3 ? out.C / 3 : 0};
+        if (x3 ? launch_cvt_out_x3(co, s) : launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
     }
     HIPCHK(hipStreamSynchronize(s));
     return 0;

@@ -12,7 +12,12 @@
 
 namespace smk {
 
-enum { DT_F32 = 0, DT_F16 = 1 };
+// DT_F16X3 (round 6): the argmax-exact fp16 context.  Every value of the track path's trunk (stem .. cls / loc head.3) is a PAIR of fp16
+// planes hi = fp16(v), lo = fp16(v - hi), and a product x * w is the three MFMA products x_hi w_hi + x_hi w_lo + x_lo w_hi in the fp32
+// accumulator (x_lo w_lo, 2^-22 relative, is dropped).  Stored as THREE channel planes [hi | hi | lo] against weights packed [w_hi | w_lo |
+// w_hi] per tap, a convolution is the SAME implicit GEMM with K tripled: the fp16 kernels run unchanged (the matrix pipe keeps fp16
+// denormals, tools/measure/gpu_denorm_probe.py), only the epilogue splits.  Kernels see DT_F16; the engine's dtype says which packs exist.
+enum { DT_F32 = 0, DT_F16 = 1, DT_F16X3 = 2 };
 enum { RES_NONE = 0, RES_PRE_RELU = 1, RES_POST_RELU = 2 };
 enum { OUT_NHWC = 0, OUT_NCHW_F32 = 1 };
 
@@ -65,6 +70,12 @@ struct ConvParams {
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
     // split-K across workgroups (NHWC epilogue): scratch for the f32 partial tiles and one arrival counter per
     // tile (zero between launches); ksplit is decided at launch (launch_conv_mfma_batch), 1 = off
+    // DT_F16X3 contexts (NHWC epilogue of conv_igemm_kernel): x3_out > 0 = the output is a split tensor -- channel n goes to n (hi), n + x3_out
+    // (hi again) and n + 2 x3_out (lo = v - hi); x3_res > 0 = the residual is one: value = res[n] + res[n + 2 x3_res].  Plane strides in channels.
+    int x3_out, x3_res;
+    const float *oscale;   // DT_F16X3: [Npad] f32 or nullptr -- the accumulator of channel n is multiplied by oscale[n] in front of the bias.  The rows of a
+                           // split pack are scaled by powers of two (max |w| of a row -> [2^13, 2^14)) so that w_lo stays a NORMAL fp16 number
+                           // (unscaled, BN-folded weights of 1e-2 .. 1e-3 leave it subnormal: 3e-6 .. 3e-5 relative instead of 2^-22); oscale undoes it, exactly
     int ksplit;
     float *ks_part;
     unsigned *ks_cnt;
@@ -107,6 +118,8 @@ struct SeqLayer {
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
+    static constexpr int x3_out = 0, x3_res = 0;           // (split-operand tensors never run inside a sequence)
+    static constexpr const float *oscale = nullptr;
 };
 static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
 // pair codes (engine.cpp seq_fuse_pairs, c3c1_tile.inc): a Bottleneck's conv3 and the 1x1 convolution that reads its output run as
@@ -210,6 +223,9 @@ struct Tuning {
     int corr_head = 1;         // fp16: dw_xcorr + head.0 + cls / loc head.3 as ONE launch (corr_head.hip); 0 = the three launches of rounds 1-3
     int seq_yres = 1;          // sequences, batches of at most 8 (one image per team): the fused pairs' trunk image Y stays in LDS from Bottleneck to
                                // Bottleneck (no 64 KB re-fetch per CU and pair, no store of a tensor only the same workgroup reads); bit-identical
+    int seq_search = 0;        // sequences (search branch): conv_search (N-fused, 128 x 256 tiles) as the persistent launch's LAST record instead of a launch
+                               // of its own behind it.  Measured a wash (0.5499-0.5521 against 0.5501-0.5505 ms per B = 8 step: 34 us inside the sequence
+                               // for the 36 us launch, profiles/r06i_seq_search_ab.txt): off
     int seq_pair2d = 0;        // sequences: the fused (conv3, next 1x1) pairs as a 2-D split over a PAIR of CUs (c3c1p_tile.inc: 64-row tiles,
                                // each CU half of conv3's channels + the matching K half of the second convolution, fp32 partial sums
                                // exchanged): 0 = c3c1_tile (one CU, 32 rows, all channels), 1 = every pair, 2 = layer3's pairs only
@@ -320,13 +336,13 @@ struct CorrHeadParams {
 };
 int launch_corr_head(const CorrHeadParams &p, void *stream);
 
-struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; };
+struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; int x3; };     // x3: C logical channels stored as [hi | hi | lo] planes (3 C per pixel)
 // the fused stem (stem_pool.hip): NCHW f32 frame -> conv1 7x7/2 + BN + ReLU -> p0 [B][s0][s0][64] -> maxpool 3x3/2 p1 -> x1 [B][s1][s1][64], f16
 struct StemPoolParams { const float *in; const void *wgt_frag; const float *bias; void *p0; void *x1; int B, S, s0, s1, Kpad; };
 
-struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; };  // NCHW f32 -> NHWC dtype
+struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; int x3; };  // NCHW f32 -> NHWC dtype (x3: [hi | hi | lo] planes of Cpad channels)
 // pairs = 1 (stem input, C <= 4): [B][H][ceil(W/2)][2 pixels x 4 channels], missing pixel / channel = 0
-struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; };  // NHWC dtype -> NCHW f32
+struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; int plane; };  // NHWC dtype -> NCHW f32 (plane > 0: split tensor, value = hi + lo at coff + 2 plane)
 
 // on-device restatement of the host decode of tools/test.py:205-254 (one workgroup per stream)
 struct DecodeParams {
@@ -441,6 +457,9 @@ int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch
 int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
+// DT_F16X3 (x3_kernels.hip): x [B][H][W][3 Cx], k [B][kh][kw][3 Cx] in whole-tensor planes (stride Cx = p.Cs), C = channels computed; out
+// [B][Ho][Wo][3 Cx] PER-BRANCH planes: logical channel c = 256 g + cc lives at 768 g + 256 plane + cc (head.0 is a grouped convolution)
+int launch_xcorr_x3(const XcorrParams &p, void *stream);
 void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);
 int launch_stem_pool(const StemPoolParams &p, void *stream);
@@ -456,6 +475,9 @@ struct L1BlockParams {
 int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);
 int launch_cvt_out(const CvtOutParams &p, int dtype, void *stream);
+int launch_cvt_in_x3(const CvtInParams &p, void *stream);       // x3_kernels.hip
+int launch_cvt_out_x3(const CvtOutParams &p, void *stream);
+int launch_maxpool_x3(const PoolParams &p, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
 int launch_ring_commit(const RingParams &p, void *stream);
 // pipelined frame steps: in-stream gate (waits for the previous frame's tail) / the tail's completion mark; cnt = device [2] u32

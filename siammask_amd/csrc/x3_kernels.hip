@@ -1,0 +1,127 @@
+// x3_kernels.hip -- the glue kernels of DT_F16X3 contexts (smk_kernels.h): values as [hi | hi | lo] fp16 channel planes.
+// The convolutions are the fp16 implicit-GEMM kernels on a tripled K (conv_igemm.hip's epilogue splits); what is here is everything
+// that is NOT a convolution on the track path: the frame -> split NHWC (tools/test.py:105-112 hands the crop over as float32), the
+// stem's max-pool (experiments/siammask_sharp/resnet.py:158), the depth-wise cross-correlation (models/rpn.py:32-38), and the read-back of
+// a split tensor for the parity tests.  All arithmetic on hi + lo in fp32; none of these is a hot kernel (the context's time is its
+// convolutions), so they are written for clarity: one thread per output value, coalesced along the channels.
+#include <hip/hip_runtime.h>
+#include "smk_kernels.h"
+
+namespace smk {
+
+namespace {
+__device__ __forceinline__ void x3_split(const float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void cvt_in_x3_kernel(const CvtInParams p) {
+    const long hw = (long)p.H * p.W, total = (long)p.B * hw * p.Cpad;
+    _Float16 *out = (_Float16 *)p.out;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % p.Cpad);
+        const long pix = idx / p.Cpad;
+        const int b = (int)(pix / hw);
+        const long yx = pix - (long)b * hw;
+        const float v = e < p.C ? p.in[((size_t)b * p.C + e) * hw + yx] : 0.f;
+        _Float16 hi, lo;
+        x3_split(v, hi, lo);
+        _Float16 *o = out + (size_t)pix * 3 * p.Cpad + e;
+        o[0] = hi; o[p.Cpad] = hi; o[2 * p.Cpad] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void cvt_out_x3_kernel(const CvtOutParams p) {
+    const long hw = (long)p.H * p.W, total = (long)p.B * p.C * hw;
+    const _Float16 *in = (const _Float16 *)p.in;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long yx = idx % hw;
+        const long t = idx / hw;
+        const int c = (int)(t % p.C), b = (int)(t / p.C);
+        const _Float16 *s = in + ((size_t)b * hw + yx) * p.Cs + p.coff + c;
+        p.out[idx] = (float)s[0] + (float)s[2 * p.plane];
+    }
+}
+
+// maxpool 3x3 stride 2 pad 1 on a split tensor: the maximum of hi + lo (exact in fp32), split again
+__global__ __launch_bounds__(256) void maxpool_x3_kernel(const PoolParams p) {
+    const long total = (long)p.B * p.Ho * p.Wo * p.C;
+    const _Float16 *in = (const _Float16 *)p.in;
+    _Float16 *out = (_Float16 *)p.out;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % p.C);
+        long t = idx / p.C;
+        const int ox = (int)(t % p.Wo); t /= p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        float m = -3.0e38f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const _Float16 *s = in + ((size_t)(b * p.H + iy) * p.W + ix) * 3 * p.C + c;
+                const float v = (float)s[0] + (float)s[2 * p.C];
+                m = v > m ? v : m;
+            }
+        }
+        _Float16 hi, lo;
+        x3_split(m, hi, lo);
+        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * p.C + c;
+        o[0] = hi; o[p.C] = hi; o[2 * p.C] = lo;
+    }
+}
+
+// depth-wise cross-correlation (models/rpn.py:32-38 conv2d_dw_group) of split tensors, fp32 FMA chain in (ky, kx) order
+__global__ __launch_bounds__(256) void dw_xcorr_x3_kernel(const XcorrParams p) {
+    const long total = (long)p.B * p.Ho * p.Wo * p.C;
+    const _Float16 *x = (const _Float16 *)p.x, *k = (const _Float16 *)p.k;
+    _Float16 *out = (_Float16 *)p.out;
+    const int Cx = p.Cs;                                   // plane stride of x / k (all branches laid out)
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % p.C);
+        long t = idx / p.C;
+        const int ox = (int)(t % p.Wo); t /= p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        float acc = 0.f;
+        for (int ky = 0; ky < p.kh; ++ky)
+            for (int kx = 0; kx < p.kw; ++kx) {
+                const _Float16 *xs = x + ((size_t)(b * p.H + oy + ky) * p.W + ox + kx) * 3 * Cx + c;
+                const _Float16 *ks = k + ((size_t)(b * p.kh + ky) * p.kw + kx) * 3 * Cx + c;
+                acc = __builtin_fmaf((float)xs[0] + (float)xs[2 * Cx], (float)ks[0] + (float)ks[2 * Cx], acc);
+            }
+        _Float16 hi, lo;
+        x3_split(acc, hi, lo);
+        const int g = c >> 8, cc = c & 255;
+        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * Cx + g * 768 + cc;
+        o[0] = hi; o[256] = hi; o[512] = lo;
+    }
+}
+
+static int grid_for(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 32768 ? 32768 : b));
+}
+
+int launch_cvt_in_x3(const CvtInParams &p, void *stream) {
+    hipLaunchKernelGGL(cvt_in_x3_kernel, dim3(grid_for((long)p.B * p.H * p.W * p.Cpad)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_cvt_out_x3(const CvtOutParams &p, void *stream) {
+    hipLaunchKernelGGL(cvt_out_x3_kernel, dim3(grid_for((long)p.B * p.C * p.H * p.W)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_maxpool_x3(const PoolParams &p, void *stream) {
+    hipLaunchKernelGGL(maxpool_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+int launch_xcorr_x3(const XcorrParams &p, void *stream) {
+    if ((p.C & 255) || p.Cs < p.C) return -1;
+    hipLaunchKernelGGL(dw_xcorr_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+}  // namespace smk

@@ -57,8 +57,10 @@ class Custom(nn.Module):
     """Base of the three variants.  Constructor signature follows the reference:
     ``Custom(pretrain=False, anchors=<dict>)``; extra keyword-only knobs:
 
-    dtype      'f32' (default; the reference's precision) or 'f16' (fp16 storage, fp32
-               accumulate).  Env override: SIAMMASK_AMD_DTYPE.
+    dtype      'f32' (default; the reference's precision), 'f16' (fp16 storage, fp32 accumulate) or
+               'f16x3' (split-operand fp16: every value of the track path's trunk is an fp16 hi + lo pair,
+               a product three MFMA products -- the argmax box index of the fp64 reference on the fp16
+               matrix pipe; mask head and Refine in plain fp16).  Env override: SIAMMASK_AMD_DTYPE.
     max_batch  streams tracked in lock-step by this instance (default 1, grows on demand).
     graph      replay captured hipGraphs (default: env SIAMMASK_AMD_GRAPH, else on).
     lazy_mask  sharp only: skip the 3969-channel mask head in track_mask (its result is never

@@ -9,7 +9,8 @@ Model (QuantOracle with q16 replaced):
   conv     -> conv(x_hi, w_hi + w_lo) + conv(x_lo, w_hi): exactly the three products the kernel would issue (x_lo * w_lo never formed);
              sums exact here (fp32 on the device: the fp32 context, with the same accumulators, is 1024 / 1024);
   the rest -> as QuantOracle (BN folded in float64, fp32 bias, ReLU / residual / maxpool / dw-xcorr on the stored values).
-Variants: "x3" as above; "x2w" = weights split, activations single fp16 (two products); "x2a" = activations split, weights single fp16:
+Variants: "x3" as above; "x3u" = the same with the lo planes stored UNSCALED (fp16 subnormals carry them: absolute precision 2^-25) -- the form
+a K-concatenated fp16 GEMM [x_hi | x_hi | x_lo] x [w_hi | w_lo | w_hi] can consume with the existing kernels; "x2w" = weights split, activations single fp16 (two products); "x2a" = activations split, weights single fp16:
 they tell WHICH rounding flips the picks if x3 is not exact.
 
 Usage: python tools/measure/cpu_split_operand_study.py [variant,...] [streams_per_(kind,seed) | "mism"] [out.json]
@@ -30,9 +31,12 @@ from siammask_amd import synth                          # noqa: E402
 _q16 = O.q16
 
 
+LO_SCALE = 2048.0       # 2^11 keeps lo out of the fp16 subnormals; 1.0 = lo stored unscaled (subnormals: absolute precision 2^-25)
+
+
 def split(a):
     hi = _q16(a)
-    lo = _q16((np.asarray(a, np.float64) - hi) * 2048.0) / 2048.0
+    lo = _q16((np.asarray(a, np.float64) - hi) * LO_SCALE) / LO_SCALE
     return hi, lo
 
 
@@ -81,7 +85,9 @@ class SplitOracle(O.QuantOracle):
 
 
 def run_variant(name, streams, sd, golden):
-    wsplit, asplit = {"x3": (True, True), "x2w": (True, False), "x2a": (False, True), "f16": (False, False)}[name]
+    global LO_SCALE
+    LO_SCALE = 1.0 if name.endswith("u") else 2048.0              # "x3u": the lo planes unscaled (what a K-concatenated fp16 GEMM can consume as is)
+    wsplit, asplit = {"x3": (True, True), "x3u": (True, True), "x2w": (True, False), "x2a": (False, True), "f16": (False, False)}[name]
     o = SplitOracle(sd, wsplit, asplit)
     saved = O.q16
     O.q16 = (lambda a: qsplit(a)) if asplit else saved             # every other rounding point of QuantOracle (cvt_in, corr, ...)
