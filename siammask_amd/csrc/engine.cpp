@@ -1916,7 +1916,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
 // part: 0 = all of it; 1 = the window convolutions + deconv + v*.2 (what reads the kept features and the position); 2 = the chain launch
 // (what reads only part 1's outputs and, for the mask head, head0).  The split exists for the fp16 chain path only (depth-2 pipelining).
 static bool refine_splittable(const smk_ctx *c, int B) {
-    return c->dtype == DT_F16 && g_tune.chain && !parallel_ok(c) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
+    return kdtype(c->dtype) == DT_F16 && g_tune.chain && !parallel_ok(c) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
 }
 static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0) {
     const int *pos = c->pos_dev;
@@ -1962,7 +1962,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0
         CHK(run_conv(c, "deconv", corr, &d1, B, od, s));
     }
     Act d = act(c, "rf_d", 15, 15, 32);
-    if (c->dtype == DT_F16 && g_tune.chain && !par) {
+    if (kdtype(c->dtype) == DT_F16 && g_tune.chain && !par) {       // (split-operand contexts: Refine is plain fp16 on the hi planes -- same launches)
         // fp16: v*.2 in one merged launch (they only depend on v*.0), then the nine sequential convolutions
         // h2 -> post0 -> h1 -> post1 -> h0 -> post2 as ONE launch with the activations in LDS (refine_chain.hip)
         if (!merged && part != 2) {
@@ -2792,7 +2792,7 @@ static int step_track_decode(smk_ctx *c, const float *x, int B, int flags, const
     // sharp fp16 with Refine: the mask head rides in the Refine chain launch (see chain_mask_kernel)
     c->have_deferred_mask = false;
     c->defer_mask_req = refine_out && mask && (flags & SMK_TRACK_MASK) && !(flags & SMK_TRACK_NO_MASK_HEAD) &&
-                        c->dtype == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
+                        kdtype(c->dtype) == DT_F16 && g_tune.chain && g_tune.chain_mask && !parallel_ok(c) &&
                         (B <= 16 ||   // measured (profiles/r02_chain_mask_ab.txt): B=8 -6.6 %, B=1 -2 %, B=64 +1 % (64 chain workgroups)
                          (c->pipe_two && PIPE_TWO_FORM == 1));      // depth-2 pipelining, form 1: the tail's first part launches it (step_tail)
     int rc2 = seq_track(c, x, B, flags, cls, loc, mask, st, defer_mask_join, phase);

@@ -16,19 +16,28 @@ __device__ __forceinline__ void x3_split(const float v, _Float16 &hi, _Float16 &
 }
 }  // namespace
 
+// one thread per (pixel, octet of channels): plane-coalesced reads, three 16-byte writes
 __global__ __launch_bounds__(256) void cvt_in_x3_kernel(const CvtInParams p) {
-    const long hw = (long)p.H * p.W, total = (long)p.B * hw * p.Cpad;
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int oct = p.Cpad >> 3;
+    const long hw = (long)p.H * p.W, npix = (long)p.B * hw, total = npix * oct;
     _Float16 *out = (_Float16 *)p.out;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int e = (int)(idx % p.Cpad);
-        const long pix = idx / p.Cpad;
+        const long pix = idx % npix;                       // pixel-major: the plane reads of a wave coalesce
+        const int q = (int)(idx / npix);
         const int b = (int)(pix / hw);
         const long yx = pix - (long)b * hw;
-        const float v = e < p.C ? p.in[((size_t)b * p.C + e) * hw + yx] : 0.f;
-        _Float16 hi, lo;
-        x3_split(v, hi, lo);
-        _Float16 *o = out + (size_t)pix * 3 * p.Cpad + e;
-        o[0] = hi; o[p.Cpad] = hi; o[2 * p.Cpad] = lo;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = q * 8 + e;
+            const float v = ch < p.C ? p.in[((size_t)b * p.C + ch) * hw + yx] : 0.f;
+            _Float16 h, l;
+            x3_split(v, h, l);
+            hi[e] = h; lo[e] = l;
+        }
+        _Float16 *o = out + (size_t)pix * 3 * p.Cpad + q * 8;
+        *(half8 *)o = hi; *(half8 *)(o + p.Cpad) = hi; *(half8 *)(o + 2 * p.Cpad) = lo;
     }
 }
 
@@ -44,18 +53,22 @@ __global__ __launch_bounds__(256) void cvt_out_x3_kernel(const CvtOutParams p) {
     }
 }
 
-// maxpool 3x3 stride 2 pad 1 on a split tensor: the maximum of hi + lo (exact in fp32), split again
+// maxpool 3x3 stride 2 pad 1 on a split tensor: the maximum of hi + lo (exact in fp32), split again; eight channels per thread
 __global__ __launch_bounds__(256) void maxpool_x3_kernel(const PoolParams p) {
-    const long total = (long)p.B * p.Ho * p.Wo * p.C;
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int cv = p.C >> 3;
+    const long total = (long)p.B * p.Ho * p.Wo * cv;
     const _Float16 *in = (const _Float16 *)p.in;
     _Float16 *out = (_Float16 *)p.out;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % p.C);
-        long t = idx / p.C;
+        const int c = (int)(idx % cv) << 3;
+        long t = idx / cv;
         const int ox = (int)(t % p.Wo); t /= p.Wo;
         const int oy = (int)(t % p.Ho);
         const int b = (int)(t / p.Ho);
-        float m = -3.0e38f;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
         for (int dy = 0; dy < 3; ++dy) {
             const int iy = oy * 2 - 1 + dy;
             if ((unsigned)iy >= (unsigned)p.H) continue;
@@ -63,41 +76,63 @@ __global__ __launch_bounds__(256) void maxpool_x3_kernel(const PoolParams p) {
                 const int ix = ox * 2 - 1 + dx;
                 if ((unsigned)ix >= (unsigned)p.W) continue;
                 const _Float16 *s = in + ((size_t)(b * p.H + iy) * p.W + ix) * 3 * p.C + c;
-                const float v = (float)s[0] + (float)s[2 * p.C];
-                m = v > m ? v : m;
+                const half8 h = *(const half8 *)s, l = *(const half8 *)(s + 2 * p.C);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)h[e] + (float)l[e];
+                    m[e] = v > m[e] ? v : m[e];
+                }
             }
         }
-        _Float16 hi, lo;
-        x3_split(m, hi, lo);
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h, l;
+            x3_split(m[e], h, l);
+            hi[e] = h; lo[e] = l;
+        }
         _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * p.C + c;
-        o[0] = hi; o[p.C] = hi; o[2 * p.C] = lo;
+        *(half8 *)o = hi; *(half8 *)(o + p.C) = hi; *(half8 *)(o + 2 * p.C) = lo;
     }
 }
 
-// depth-wise cross-correlation (models/rpn.py:32-38 conv2d_dw_group) of split tensors, fp32 FMA chain in (ky, kx) order
+// depth-wise cross-correlation (models/rpn.py:32-38 conv2d_dw_group) of split tensors: eight channels per thread (16-byte loads of the
+// hi and lo planes of both operands), an fp32 FMA chain per channel in (ky, kx) order on hi + lo
 __global__ __launch_bounds__(256) void dw_xcorr_x3_kernel(const XcorrParams p) {
-    const long total = (long)p.B * p.Ho * p.Wo * p.C;
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int cv = p.C >> 3;                               // channel octets computed
+    const long total = (long)p.B * p.Ho * p.Wo * cv;
     const _Float16 *x = (const _Float16 *)p.x, *k = (const _Float16 *)p.k;
     _Float16 *out = (_Float16 *)p.out;
     const int Cx = p.Cs;                                   // plane stride of x / k (all branches laid out)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % p.C);
-        long t = idx / p.C;
+        const int c = (int)(idx % cv) << 3;
+        long t = idx / cv;
         const int ox = (int)(t % p.Wo); t /= p.Wo;
         const int oy = (int)(t % p.Ho);
         const int b = (int)(t / p.Ho);
-        float acc = 0.f;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         for (int ky = 0; ky < p.kh; ++ky)
             for (int kx = 0; kx < p.kw; ++kx) {
                 const _Float16 *xs = x + ((size_t)(b * p.H + oy + ky) * p.W + ox + kx) * 3 * Cx + c;
                 const _Float16 *ks = k + ((size_t)(b * p.kh + ky) * p.kw + kx) * 3 * Cx + c;
-                acc = __builtin_fmaf((float)xs[0] + (float)xs[2 * Cx], (float)ks[0] + (float)ks[2 * Cx], acc);
+                const half8 xh = *(const half8 *)xs, xl = *(const half8 *)(xs + 2 * Cx);
+                const half8 kh8 = *(const half8 *)ks, kl = *(const half8 *)(ks + 2 * Cx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] = __builtin_fmaf((float)xh[e] + (float)xl[e], (float)kh8[e] + (float)kl[e], acc[e]);
             }
-        _Float16 hi, lo;
-        x3_split(acc, hi, lo);
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (_Float16)acc[e];
+            lo[e] = (_Float16)(acc[e] - (float)hi[e]);
+        }
         const int g = c >> 8, cc = c & 255;
         _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * Cx + g * 768 + cc;
-        o[0] = hi; o[256] = hi; o[512] = lo;
+        *(half8 *)o = hi; *(half8 *)(o + 256) = hi; *(half8 *)(o + 512) = lo;
     }
 }
 
@@ -107,7 +142,8 @@ static int grid_for(long total) {
 }
 
 int launch_cvt_in_x3(const CvtInParams &p, void *stream) {
-    hipLaunchKernelGGL(cvt_in_x3_kernel, dim3(grid_for((long)p.B * p.H * p.W * p.Cpad)), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.Cpad & 7) return -1;
+    hipLaunchKernelGGL(cvt_in_x3_kernel, dim3(grid_for((long)p.B * p.H * p.W * (p.Cpad >> 3))), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_cvt_out_x3(const CvtOutParams &p, void *stream) {
@@ -115,12 +151,13 @@ int launch_cvt_out_x3(const CvtOutParams &p, void *stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_maxpool_x3(const PoolParams &p, void *stream) {
-    hipLaunchKernelGGL(maxpool_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    if (p.C & 7) return -1;
+    hipLaunchKernelGGL(maxpool_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * (p.C >> 3))), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 int launch_xcorr_x3(const XcorrParams &p, void *stream) {
     if ((p.C & 255) || p.Cs < p.C) return -1;
-    hipLaunchKernelGGL(dw_xcorr_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(dw_xcorr_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * (p.C >> 3))), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
