@@ -501,75 +501,81 @@ __device__ __forceinline__ void decode_tail(const DecodeParams &p, const int a, 
         best_i = a * SS + rem;
         box[0] = cx; box[1] = cy; box[2] = w; box[3] = h; box[4] = score; box[5] = penalty;
     }
-    __shared__ double sv[DEC_THREADS];
-    __shared__ int si[DEC_THREADS];
-    sv[threadIdx.x] = best;
-    si[threadIdx.x] = best_i;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s && (int)threadIdx.x + s < DEC_THREADS) {
-            const double v = sv[threadIdx.x + s];
-            const int j = si[threadIdx.x + s];
-            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && j < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = j; }
-        }
-        __syncthreads();
+    // ---- the workgroup's winner: butterfly inside each wave (value, then lowest index), ten partials through LDS (round 6: the first version
+    //      walked a 640-entry LDS tree -- ten barriers -- and its last arriver finished the frame on ONE lane, a chain of dependent round trips)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double wb = best;
+    int wi = best_i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(wb, off);
+        const int oi = __shfl_xor(wi, off);
+        if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
     }
-    __shared__ int s_last;
-    if (best_i == si[0]) {                           // this workgroup's winner (indices are unique)
+    __shared__ double sv[DEC_THREADS / 64];
+    __shared__ int si[DEC_THREADS / 64];
+    __shared__ int s_last, s_row;
+    if (lane == 0) { sv[wv] = wb; si[wv] = wi; }
+    if (threadIdx.x == 0 && p.ring_box && p.box_out)        // the ring's row: the cursor was advanced by the previous frame's last launch (a plain read, early)
+        s_row = (int)(*(volatile const unsigned *)p.ring_cursor % (unsigned)p.ring_rows);   // unsigned: no negative row after 2^31 frames
+    __syncthreads();
+    double gb = sv[0];
+    int gi = si[0];
+#pragma unroll
+    for (int w2 = 1; w2 < DEC_THREADS / 64; ++w2)
+        if (sv[w2] > gb || (sv[w2] == gb && si[w2] < gi)) { gb = sv[w2]; gi = si[w2]; }
+    if (best_i == gi) {                              // this workgroup's winner (indices are unique)
         // device-coherent (sc1) stores + vmcnt(0) instead of a release fence: an agent-scope fence writes back
-        // and invalidates the XCD's whole L2
+        // and invalidates the XCD's whole L2.  One 64-byte record per (stream, anchor shape): box[0..5], best, best_i.
         unsigned long long *pb = (unsigned long long *)(p.part_box + ((size_t)b * 8 + a) * 8);
         for (int q = 0; q < 6; ++q)
             __hip_atomic_store(pb + q, (unsigned long long)__double_as_longlong(box[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pb + 6, (unsigned long long)__double_as_longlong(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pb + 7, (unsigned long long)__double_as_longlong((double)best_i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((unsigned long long *)(p.part_val + b * 8 + a), (unsigned long long)__double_as_longlong(best),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.part_idx + b * 8 + a, best_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // published before announcing arrival
         const unsigned prev = __hip_atomic_fetch_add(p.arrived + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == (unsigned)p.A - 1;
     }
     __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
-    // last workgroup of this stream: pick among the A winners (device-coherent loads)
+    if (!s_last || wv != 0) return;
+    // ---- last workgroup of this stream, its first WAVE: lane l loads element l & 7 of record l >> 3 -- all A records in ONE round trip (device-
+    //      coherent loads) -- then every lane picks the winner from the shuffled (value, index) pairs and lanes 0..7 write the row
+    const int rq = lane >> 3, re = lane & 7;
+    double rec = 0.0;
+    if (rq < p.A) {
+        const unsigned long long raw = __hip_atomic_load((const unsigned long long *)(p.part_box + ((size_t)b * 8 + rq) * 8) + re, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        rec = __longlong_as_double((long long)raw);
+    }
     double bv = -1e300;
     int bi = 0x7fffffff, ba = 0;
     for (int q = 0; q < p.A; ++q) {
-        const unsigned long long raw = __hip_atomic_load((const unsigned long long *)(p.part_val + b * 8 + q), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-        const double v = __longlong_as_double((long long)raw);
-        const int j = __hip_atomic_load(p.part_idx + b * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v = __shfl(rec, 8 * q + 6);
+        const int j = (int)__shfl(rec, 8 * q + 7);
         if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; ba = q; }
     }
+    const double mine = __shfl(rec, 8 * ba + (lane & 7));          // lane l < 8: element l of the winning record
     const int rm = bi - (bi / SS) * SS, y = rm / p.S, x = rm - y * p.S;
-    if (p.pos_out) {
+    if (lane == 0 && p.pos_out) {
         // (device-coherent stores: with p.mark set, the Refine tail of a pipelined step reads the position from the side stream as soon
         //  as the mark below is visible -- before this kernel's end has written the XCD's L2 back)
         __hip_atomic_store(p.pos_out + 2 * b, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p.pos_out + 2 * b + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (p.box_out) {
-        const unsigned long long *pb = (const unsigned long long *)(p.part_box + ((size_t)b * 8 + ba) * 8);
-        double *o = p.box_out + 8 * b;
-        for (int q = 0; q < 8; ++q)
-            o[q] = __longlong_as_double((long long)__hip_atomic_load(pb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (lane < 8 && p.box_out) {
+        p.box_out[8 * b + lane] = mine;
+        // result ring: this frame's box also goes to the ring's current row
+        if (p.ring_box) p.ring_box[((size_t)s_row * p.B + b) * 8 + lane] = mine;
     }
-    if (p.ring_box && p.box_out) {
-        // result ring: this frame's box also goes to the ring's current row (the cursor was advanced by the previous frame's
-        // last launch: a plain read).  Without a Refine launch behind it the last stream to get here advances the cursor --
-        // every other stream's writer has read it before its own arrival.
-        const int row = (int)(*(volatile const unsigned *)p.ring_cursor % (unsigned)p.ring_rows);   // unsigned: no negative row after 2^31 frames
-        double *r = p.ring_box + ((size_t)row * p.B + b) * 8;
-        const double *o = p.box_out + 8 * b;
-        for (int q = 0; q < 8; ++q) r[q] = o[q];
-        if (p.ring_advance) {
-            const unsigned prev = __hip_atomic_fetch_add(p.ring_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (prev == (unsigned)p.B - 1) {
-                __hip_atomic_store(p.ring_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(p.ring_cursor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (p.ring_also) __hip_atomic_fetch_add(p.ring_also, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+    if (lane != 0) return;
+    if (p.ring_box && p.box_out && p.ring_advance) {
+        // Without a Refine launch behind it the last stream to get here advances the cursor -- every other stream's writer has read it
+        // (at its start) before its own arrival.
+        const unsigned prev = __hip_atomic_fetch_add(p.ring_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (unsigned)p.B - 1) {
+            __hip_atomic_store(p.ring_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.ring_cursor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.ring_also) __hip_atomic_fetch_add(p.ring_also, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __hip_atomic_store(p.arrived + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

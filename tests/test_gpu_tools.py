@@ -10,6 +10,7 @@ whole loop -- glob frames, selectROI, siamese_init, siamese_track(mask_enable=Tr
   control : the reference's own Custom on the host CPU cores (GPU hidden from that process).
 
 Gate (fp32): per frame target_pos / target_sz within 0.5 px, score within 1e-3, thresholded full-frame mask IoU >= 0.99.
+f16x3 (split-operand fp16, round 6): the same box gates as fp32 on EVERY frame of the free-running trajectory; masks at IoU >= 0.97.
 fp16 (SIAMMASK_AMD_DTYPE=f16) is gated on the FIRST tracked frame only (same incoming state on both sides: 3 px, IoU >= 0.97):
 the tracker is free-running, the synthetic checkpoint has no trained attractor, and one flipped anchor in a later frame sends
 the two trajectories apart for good -- a property of the fixture, reported in the JSON, not gated.  Needs oracle/_ref (built where
@@ -65,7 +66,7 @@ def control():
     return info, tr
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f16x3"])
 def test_unchanged_demo_drives_the_hip_path(control, dtype):
     cinfo, ctr = control
     info, tr = run_trace(os.path.join(REPO, "dropin", "sharp"), "dropin_%s" % dtype, {"SIAMMASK_AMD_DTYPE": dtype})
@@ -82,5 +83,9 @@ def test_unchanged_demo_drives_the_hip_path(control, dtype):
         json.dump(rep, f, indent=1)
     if dtype == "f32":
         assert d["pos_px"] <= 0.5 and d["sz_px"] <= 0.5 and d["score"] <= 1e-3 and d["mask_iou_min"] >= 0.99, rep
+    elif dtype == "f16x3":
+        # split-operand fp16 (round 6): the box path is fp32-grade, so the FREE-RUNNING trajectory stays on the reference's for all frames (where
+        # the fp16 context leaves it after a few); the mask comes from Refine in plain fp16 -> the fp16 IoU gate, on every frame
+        assert d["pos_px"] <= 0.5 and d["sz_px"] <= 0.5 and d["score"] <= 1e-3 and d["mask_iou_min"] >= 0.97, rep
     else:
         assert d1["pos_px"] <= 3.0 and d1["sz_px"] <= 3.0 and d1["score"] <= 5e-3 and d1["mask_iou_min"] >= 0.97, rep
