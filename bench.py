@@ -618,7 +618,18 @@ def argmax_agreement(B=64, seeds=8):
     (tools/measure/argmax_stats.py; the gate with gaps and errors is tests/test_gpu_argmax.py)."""
     sys.path.insert(0, os.path.join(REPO, "tools", "measure"))
     import argmax_stats
-    return argmax_stats.summary(argmax_stats.collect(B=B, seeds=seeds))
+    out = argmax_stats.summary(argmax_stats.collect(B=B, seeds=seeds))
+    # round 6: the split-operand fp16 context (dtype f16x3) against the same fp32 context (whose index is the fp64 oracle's on every one
+    # of these streams, tests/test_gpu_argmax.py): the rate the bit-exact configuration of the line carries
+    try:
+        m32 = argmax_stats._model("sharp", "f32", B)
+        mx3 = argmax_stats._model("sharp", "f16x3", B)
+        x3 = argmax_stats.collect(B=B, seeds=seeds, models=(mx3, m32))
+        out["f16x3_vs_fp32_context"] = {"streams": x3["streams"], "agree": x3["agree"], "rate": round(x3["rate"], 5)}
+        del m32, mx3
+    except Exception as e:  # noqa: BLE001
+        out["f16x3_vs_fp32_context"] = {"error": str(e)[:200]}
+    return out
 
 
 def free_port():
