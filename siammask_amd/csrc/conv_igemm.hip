@@ -265,6 +265,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
         auto sgpr = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
         int g_kwm = sgpr(p.kw_magic), g_kw = sgpr(p.kw), g_kh = sgpr(p.kh), g_dil = sgpr(p.dil), g_Hl = sgpr(p.Hl), g_Wl = sgpr(p.Wl),
             g_Hs = sgpr(p.Hs), g_Ws = sgpr(p.Ws), g_Cs = sgpr(p.Cs), g_cish = sgpr(p.ci_shift), g_Ci = sgpr(p.Ci), g_ups = sgpr(p.ups);
+        const int g_x3in = sgpr(p.x3_in);                  // split tensors: operand channels [hi | hi | lo] of a tap -> stored planes [hi | lo]
         asm volatile("" : "+s"(g_kwm), "+s"(g_kw), "+s"(g_kh), "+s"(g_dil), "+s"(g_Hl), "+s"(g_Wl));
         asm volatile("" : "+s"(g_Hs), "+s"(g_Ws), "+s"(g_Cs), "+s"(g_cish), "+s"(g_Ci), "+s"(g_ups));
         // (round 6: a K tile never straddles a tap whenever Ci is a MULTIPLE of the tile, power of two or not -- the split-operand
@@ -310,6 +311,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
                 else { tap = k / g_Ci; cur_c = k - tap * g_Ci; }
                 tap_offsets(tap);
             }
+            if (g_x3in > 0 && cur_c >= g_x3in) cur_c -= g_x3in;
         };
         // all NP pieces of K tile kt into ring slot `buf`
         auto issue_tile = [&](int kt, int buf) {
@@ -457,7 +459,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
                     if constexpr (sizeof(T) == 2) {
                         if (p.x3_res > 0) {                    // split residual (DT_F16X3): value = hi + lo
                             float lo[EV];
-                            TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + 2 * p.x3_res + n0 + c4, lo);
+                            TR::loadv(res + (size_t)m * p.res_Cs + p.res_coff + p.x3_res + n0 + c4, lo);
 #pragma unroll
                             for (int q = 0; q < EV; ++q) rv[ps][q] += lo[q];
                         }
@@ -589,12 +591,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvBatch &cb, const int b
                     }
                     TR::storev(out + (size_t)m * p.Cos + cout_off + n, v);
                     if constexpr (sizeof(T) == 2) {
-                        if (p.x3_out > 0) {                    // split output (DT_F16X3): [hi | hi | lo = v - hi]
+                        if (p.x3_out > 0) {                    // split output (DT_F16X3): [hi | lo = v - hi]
                             float lo[EV];
 #pragma unroll
                             for (int q = 0; q < EV; ++q) lo[q] = v[q] - (float)(_Float16)v[q];
-                            TR::storev(out + (size_t)m * p.Cos + cout_off + p.x3_out + n, v);
-                            TR::storev(out + (size_t)m * p.Cos + cout_off + 2 * p.x3_out + n, lo);
+                            TR::storev(out + (size_t)m * p.Cos + cout_off + p.x3_out + n, lo);
                         }
                     }
                 }

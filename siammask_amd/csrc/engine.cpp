@@ -108,7 +108,7 @@ struct PackedConv {
     int kw = 0;              // horizontal taps when != k (pixel-pair stem)
     int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
     float *oscale = nullptr; // DT_F16X3: device [rows] f32, the inverse of the power-of-two scale each row of the split pack carries (ConvParams::oscale)
-    bool x3 = false;         // DT_F16X3: K tripled -- per tap [w_hi | w_lo | w_hi] against activations stored [hi | hi | lo]; Ci = 3 x channels
+    bool x3 = false;         // DT_F16X3: K tripled -- per tap [w_hi | w_lo | w_hi] against the operand [hi | hi | lo] gathered from the stored planes [hi | lo]; Ci = 3 x channels
 };
 
 constexpr size_t KS_PART_FLOATS = 8u << 20;      // 32 MB: e.g. 256 tiles x 4 parts x 64x128
@@ -555,7 +555,7 @@ static const int STAGE_BLOCKS[3] = {3, 4, 6};
 static int build_weights(smk_ctx *c) {
     const std::string f = "features.features.";
     const bool x3 = c->dtype == DT_F16X3;              // the trunk of the track path in split operands; mask head + Refine stay plain fp16
-    if (x3) CHK(pack_conv(c, "stem", {bnpart(f + "conv1", f + "bn1")}, 3, 64, 7, false, true));      // (generic 7x7 on [hi | hi | lo] x 8 channels)
+    if (x3) CHK(pack_conv(c, "stem", {bnpart(f + "conv1", f + "bn1")}, 3, 64, 7, false, true));      // (generic 7x7 on the operand [hi | hi | lo] x 8 channels)
     else CHK(pack_stem(c));
     int inplanes = 64;
     for (int s = 0; s < 3; ++s) {
@@ -614,8 +614,8 @@ static int build_weights(smk_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 static int alloc_buf(smk_ctx *c, const char *name, size_t elems_per_item) {
     void *p = nullptr;
-    // (DT_F16X3: three channel planes per tensor of the trunk; the Refine buffers get them too -- small, and one rule)
-    const size_t bytes = elems_per_item * (c->dtype == DT_F16X3 ? 3 : 1) * (size_t)c->maxB * esize(c->dtype) + 256;
+    // (DT_F16X3: two channel planes [hi | lo] per tensor of the trunk; the Refine buffers get them too -- small, and one rule)
+    const size_t bytes = elems_per_item * (c->dtype == DT_F16X3 ? X3_PLANES : 1) * (size_t)c->maxB * esize(c->dtype) + 256;
     HIPCHK(hipMalloc(&p, bytes));
     HIPCHK(hipMemset(p, 0, bytes));
     c->buf[name] = p;
@@ -750,6 +750,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.Hs = in.H; p.Ws = in.W; p.Cs = in.C;
     p.cin_off = o.cin_off;
     p.Ci = pc.Ci;
+    p.x3_in = pc.x3 ? pc.Ci / 3 : 0;      // split tensor in: the operand's [hi | hi | lo] channels of a tap are gathered from the stored [hi | lo] planes
     p.Hl = (o.win || o.ups) ? o.Hl : in.H;
     p.Wl = (o.win || o.ups) ? o.Wl : in.W;
     p.org_y = o.org_y; p.org_x = o.org_x;
@@ -767,9 +768,9 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.relu = o.relu;
     p.groups = o.groups;
     if (o.groups > 1) {
-        p.g_cin_off = pc.Ci;            // branches sit side by side in the channel dimension
-        p.g_wgt_off = pc.group_rows;
-        p.g_cout_off = pc.group_rows * (pc.x3 ? 3 : 1);      // (split tensors: a branch's three planes side by side)
+        p.g_cin_off = pc.x3 ? pc.Ci / 3 * X3_PLANES : pc.Ci;      // branches sit side by side in the channel dimension (split tensors: a branch's
+        p.g_wgt_off = pc.group_rows;                               //  two stored planes side by side; pc.Ci is the OPERAND's channel count, 3 per value)
+        p.g_cout_off = pc.group_rows * (pc.x3 ? X3_PLANES : 1);
     }
     if (o.nchw_out) {
         p.out = o.nchw_out;
@@ -785,9 +786,9 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         p.cout_off = o.cout_off;
         p.Nst = rup(p.N, 8);
         if (pc.x3) {
-            // split output: whole-tensor planes (stride = a third of the buffer's channels), per-branch planes for a grouped launch
-            p.x3_out = o.groups > 1 ? pc.group_rows : out->C / 3;
-            if (out->C % 3 || o.cout_off + (o.groups - 1) * 3 * pc.group_rows + 2 * p.x3_out + p.Nst > out->C)
+            // split output: whole-tensor planes (stride = half of the buffer's channels), per-branch planes for a grouped launch
+            p.x3_out = o.groups > 1 ? pc.group_rows : out->C / X3_PLANES;
+            if (out->C % X3_PLANES || o.cout_off + (o.groups - 1) * X3_PLANES * pc.group_rows + p.x3_out + p.Nst > out->C)
                 return fail(SMK_E_ARG, "internal: split conv output channels exceed buffer");
         } else if (o.cout_off + (o.groups - 1) * pc.group_rows + p.Nst > out->C)
             return fail(SMK_E_ARG, "internal: conv output channels exceed buffer");
@@ -820,7 +821,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
         p.res_Cs = o.res->C;
         p.res_coff = o.res_coff;
         p.res_mode = o.res_mode;
-        if (pc.x3) p.x3_res = o.res->C / 3;
+        if (pc.x3) p.x3_res = o.res->C / X3_PLANES;
     }
     p.ksplit = 1;
     p.ks_part = c->ks_part;
@@ -1606,8 +1607,8 @@ enum { PH_FRONT = 1, PH_BACK = 2, PH_ALL = 3 };
 // sequence where the stand-alone launch needs 0.9.  *search_done tells the caller that conv_search has been issued (recorded or launched).
 static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s, int phase = PH_ALL, int search_nb = 0, int search_nbt = 0,
                         bool *search_done = nullptr) {
-    // DT_F16X3: the trunk's tensors are [hi | hi | lo] planes -- three times the channels (smk_kernels.h)
-    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    // DT_F16X3: the trunk's tensors are stored as [hi | lo] planes -- twice the channels (smk_kernels.h)
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? X3_PLANES * C : C; };
     const int s0 = (S - 7) / 2 + 1;          // conv1 7x7 s2 p0
     const int s1 = (s0 + 2 - 3) / 2 + 1;     // maxpool 3/2/1
     const int s2 = (s1 - 3) / 2 + 1;         // layer2 3x3 s2 p0
@@ -1624,11 +1625,11 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
                      (double)B * (3.0 * S * S * 4 + ((double)s0 * s0 + (double)s1 * s1) * 64 * 2));
         if (launch_stem_pool(sp_, s)) return fail(SMK_E_HIP, "stem_pool launch failed: %s", hipGetErrorString(hipGetLastError()));
     } else if (c->dtype == DT_F16X3) {
-        // split operands: frame -> [hi | hi | lo] x 8 channels, the 7x7 stem as a generic convolution on them, the pool on hi + lo
-        Act xin = act(c, "xin", S, S, 24);
+        // split operands: frame -> [hi | lo] x 8 channels, the 7x7 stem as a generic convolution on them, the pool on hi + lo
+        Act xin = act(c, "xin", S, S, X3_PLANES * 8);
         CvtInParams ci{x, xin.p, B, 3, S, S, 8, 0, 1};
         {
-            ProfScope ps(c, s, "cvt_in", "cvt_in_x3", 0.0, (double)B * S * S * (3 * 4 + 24 * 2));
+            ProfScope ps(c, s, "cvt_in", "cvt_in_x3", 0.0, (double)B * S * S * (3 * 4 + X3_PLANES * 8 * 2));
             if (launch_cvt_in_x3(ci, s)) return fail(SMK_E_HIP, "cvt_in_x3 launch failed");
         }
         ConvOpt o;
@@ -1636,7 +1637,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
         CHK(run_conv(c, "stem", xin, &p0, B, o, s));
         PoolParams pp{p0.p, x1.p, B, s0, s0, 64, s1, s1, 1};
         {
-            ProfScope ps(c, s, "maxpool", "maxpool_x3", 0.0, (double)B * 3 * 64 * 2 * (s0 * s0 + s1 * s1));
+            ProfScope ps(c, s, "maxpool", "maxpool_x3", 0.0, (double)B * X3_PLANES * 64 * 2 * (s0 * s0 + s1 * s1));
             if (launch_maxpool_x3(pp, s)) return fail(SMK_E_HIP, "maxpool_x3 launch failed");
         }
     } else {
@@ -1805,7 +1806,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
 }
 
 static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
-    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? X3_PLANES * C : C; };
     CHK(run_backbone(c, z, B, 127, s));
     const int nb = nbranch(c);
     Act zf = act(c, "zf", 7, 7, X(256));
@@ -1820,7 +1821,7 @@ static int seq_template(smk_ctx *c, const float *z, int B, hipStream_t s) {
 // beside the small decode / Refine launches instead of in front of them
 static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, float *loc, float *mask,
                      hipStream_t s, bool defer_mask_join = false, int phase = PH_ALL) {
-    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? X3_PLANES * C : C; };
     const bool x3 = c->dtype == DT_F16X3;
     const int nbt = nbranch(c);                                   // branches laid out in the buffers
     const int nb = (flags & SMK_TRACK_MASK) ? nbt : 2;            // branches computed
@@ -1871,7 +1872,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     {
         // algorithmic bytes per branch-item: read 256*(29*29 + 5*5), write 256*25*25 elements
         const double xb = (double)B * nb * 256.0 * (29 * 29 + 25 + 625) * esize(c->dtype);
-        ProfScope ps(c, s, "dw_xcorr", x3 ? "dw_xcorr_x3" : "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, x3 ? 3.0 * xb : xb);
+        ProfScope ps(c, s, "dw_xcorr", x3 ? "dw_xcorr_x3" : "dw_xcorr", 2.0 * B * nb * 256.0 * 625 * 25, x3 ? (double)X3_PLANES * xb : xb);
         // (split operands: xs / zk in whole-tensor planes, corr in per-branch planes -- head.0 is a grouped convolution)
         if (x3 ? launch_xcorr_x3(xp, s) : launch_xcorr(xp, kdtype(c->dtype), s)) return fail(SMK_E_HIP, "xcorr launch failed");
     }
@@ -1880,7 +1881,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     // the three head.3 convs are independent: cls / loc / mask side by side
     if (par) { CHK(stream_dep(c, s, s_loc)); if (s_cls != s) CHK(stream_dep(c, s, s_cls)); }
     ConvOpt oc; oc.nchw_out = cls; oc.cin_off = 0;
-    ConvOpt ol; ol.nchw_out = loc; ol.cin_off = x3 ? 768 : 256;
+    ConvOpt ol; ol.nchw_out = loc; ol.cin_off = x3 ? X3_PLANES * 256 : 256;      // (x3: a branch's [hi | lo] planes side by side)
     if (par) {
         CHK(run_conv(c, "cls3", h0, nullptr, B, oc, s_cls));
         CHK(run_conv(c, "loc3", h0, nullptr, B, ol, s_loc));
@@ -1889,7 +1890,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
     }
     }
     if (want_mask) {
-        ConvOpt om; om.nchw_out = mask; om.cin_off = x3 ? 2 * 768 : 512;      // (x3: plain fp16 pack on the hi plane of the mask branch)
+        ConvOpt om; om.nchw_out = mask; om.cin_off = x3 ? 2 * X3_PLANES * 256 : 512;      // (x3: plain fp16 pack on the hi plane of the mask branch)
         if (c->defer_mask_req && !par) {
             // handed to seq_refine: it runs inside the chain launch, beside the (B-workgroup) Refine chain
             auto it = c->conv.find("mask3");
@@ -1920,8 +1921,8 @@ static bool refine_splittable(const smk_ctx *c, int B) {
 }
 static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0) {
     const int *pos = c->pos_dev;
-    // (DT_F16X3: Refine runs in plain fp16 on the hi planes of the kept trunk tensors -- channel stride 3 C, first C channels)
-    auto X = [c](int C) { return c->dtype == DT_F16X3 ? 3 * C : C; };
+    // (DT_F16X3: Refine runs in plain fp16 on the hi planes of the kept trunk tensors -- channel stride 2 C, first C channels)
+    auto X = [c](int C) { return c->dtype == DT_F16X3 ? X3_PLANES * C : C; };
     Act corr = act(c, "corr", 25, 25, X(256 * 3));
     Act p0 = act(c, "p0", 125, 125, X(64)), p1 = act(c, "p1", 63, 63, X(256)), p2 = act(c, "p2", 31, 31, X(512));
     // The three window convs v2.0 / v1.0 / v0.0 (the heavy part of Refine) depend only on the
@@ -1948,7 +1949,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0
     }
     // deconv(corr_feature[:, :, y, x]) -> [15,15,32]            (:145,:149)
     Act d1 = act(c, "rf_d", 1, 1, 15 * 15 * 32);
-    ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = c->dtype == DT_F16X3 ? 2 * 768 : 512;
+    ConvOpt od; od.win = true; od.Hl = od.Wl = 1; od.pos = pos; od.pos_mul = 1; od.cin_off = c->dtype == DT_F16X3 ? 2 * X3_PLANES * 256 : 512;
     Act v2a = act(c, "rf_v2a", 15, 15, 128), v1a = act(c, "rf_v1a", 31, 31, 64), v0a = act(c, "rf_v0a", 61, 61, 16);
     const bool merged = !par && (!c->prof || c->prof_merge) && g_tune.merge && (g_tune.merge == 2 || B <= g_tune.merge_max_batch);
     if (merged && part != 2) {
@@ -3167,11 +3168,11 @@ int smk_debug_read(smk_ctx *c, const char *name, float *dst, int *C, int *H, int
             CHK(pipe_join(c, (hipStream_t)stream, true));
             c->parity_now = c->last_parity;            // p0 / p1: the copy the last tracked frame wrote
             if (c->dtype == DT_F16X3) {
-                // split tensors: value = hi + lo.  Whole-tensor planes, except corr / head0 (per-branch planes: 256 g + cc -> 768 g + cc)
+                // split tensors: value = hi + lo.  Whole-tensor planes, except corr / head0 (per-branch planes: 256 g + cc -> 512 g + cc)
                 const bool per_branch = !strcmp(e.n, "corr") || !strcmp(e.n, "head0");
                 const int ng = per_branch ? e.cn / 256 : 1, cg = e.cn / ng;
                 for (int g = 0; g < ng; ++g) {
-                    CvtOutParams p{act(c, e.b, e.h, e.w, 3 * e.cs).p, dst, c->last_B, cg, e.h, e.w, 3 * e.cs, g * 768, per_branch ? 256 : e.cs};
+                    CvtOutParams p{act(c, e.b, e.h, e.w, X3_PLANES * e.cs).p, dst, c->last_B, cg, e.h, e.w, X3_PLANES * e.cs, g * X3_PLANES * 256, per_branch ? 256 : e.cs};
                     if (ng > 1) return fail(SMK_E_ARG, "smk_debug_read: %s of a split-operand context is read per branch: not implemented", e.n);
                     if (launch_cvt_out_x3(p, stream)) return fail(SMK_E_HIP, "cvt_out launch failed");
                 }
@@ -3252,7 +3253,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
                      void *stream) {
     if (!g || !x_dev || !w_host || !y_dev) return fail(SMK_E_ARG, "smk_op_conv2d_ex: null argument");
     if (dtype != DT_F32 && dtype != DT_F16 && dtype != DT_F16X3) return fail(SMK_E_ARG, "bad dtype");
-    // DT_F16X3 (unit parity of the split-operand convolution): x, res -> [hi | hi | lo] planes, the pack tripled per tap, conv_igemm_kernel's
+    // DT_F16X3 (unit parity of the split-operand convolution): x, res -> [hi | lo] planes, the pack tripled per tap ([w_hi | w_lo | w_hi]), conv_igemm_kernel's
     // (or wreg_tile's) splitting epilogue, the output read back as hi + lo.  NHWC epilogue only, whole channel range.
     const bool x3 = dtype == DT_F16X3;
     if (x3 && (((algo & 0xff) != 0 && (algo & 0xff) != 5) || g->cin_off || g->cin_len))
@@ -3274,7 +3275,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         std::vector<float> osc;
         split_rows_x3(rows, pc.rows, K1, pc.Kpad, g->k * g->k, Ci0, osc);
         CHK(upload_oscale(pc, osc));
-        in.C *= 3;
+        in.C *= X3_PLANES;
     }
     CHK(upload_packed(pc, rows, bias, dtype));
     TmpBufs tmp;
@@ -3284,7 +3285,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     if (pc.oscale) tmp.v.push_back(pc.oscale);
     const size_t es = esize(dtype);
     CHK(tmp.alloc(&in.p, (size_t)g->B * g->H * g->W * in.C * es));
-    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, x3 ? in.C / 3 : in.C, 0, x3 ? 1 : 0};
+    CvtInParams ci{x_dev, in.p, g->B, g->Cin, g->H, g->W, x3 ? in.C / X3_PLANES : in.C, 0, x3 ? 1 : 0};
     if (x3 ? launch_cvt_in_x3(ci, s) : launch_cvt_in(ci, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
     int *pos_dev = nullptr;
     if (pos_host) {
@@ -3304,12 +3305,12 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         tmp.v.push_back(pc.w_halo);
     }
     Act out, res;
-    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8) * (x3 ? 3 : 1);
+    out.H = Ho; out.W = Wo; out.C = rup(g->Cout, 8) * (x3 ? X3_PLANES : 1);
     if (res_dev && g->res_mode) {
         if (nchw) return fail(SMK_E_ARG, "residual is not supported with the NCHW epilogue");
         res = out;
         CHK(tmp.alloc(&res.p, (size_t)g->B * Ho * Wo * out.C * es));
-        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, x3 ? out.C / 3 : out.C, 0, x3 ? 1 : 0};
+        CvtInParams cr{res_dev, res.p, g->B, g->Cout, Ho, Wo, x3 ? out.C / X3_PLANES : out.C, 0, x3 ? 1 : 0};
         if (x3 ? launch_cvt_in_x3(cr, s) : launch_cvt_in(cr, dtype, s)) return fail(SMK_E_HIP, "cvt_in launch failed");
         o.res = &res; o.res_mode = g->res_mode;
     }
@@ -3348,7 +3349,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     }
     if (rc) return fail(SMK_E_HIP, "conv launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (!nchw) {
-        CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0, x3 ? out.C / 3 : 0};
+        CvtOutParams co{out.p, y_dev, g->B, g->Cout, Ho, Wo, out.C, 0, x3 ? out.C / X3_PLANES : 0};
         if (x3 ? launch_cvt_out_x3(co, s) : launch_cvt_out(co, dtype, s)) return fail(SMK_E_HIP, "cvt_out launch failed");
     }
     HIPCHK(hipStreamSynchronize(s));

@@ -70,9 +70,12 @@ struct ConvParams {
     int nt_store;          // NCHW f32 epilogue: non-temporal stores (large tensors handed to the caller)
     // split-K across workgroups (NHWC epilogue): scratch for the f32 partial tiles and one arrival counter per
     // tile (zero between launches); ksplit is decided at launch (launch_conv_mfma_batch), 1 = off
-    // DT_F16X3 contexts (NHWC epilogue of conv_igemm_kernel): x3_out > 0 = the output is a split tensor -- channel n goes to n (hi), n + x3_out
-    // (hi again) and n + 2 x3_out (lo = v - hi); x3_res > 0 = the residual is one: value = res[n] + res[n + 2 x3_res].  Plane strides in channels.
-    int x3_out, x3_res;
+    // DT_F16X3 contexts.  A split tensor is STORED as two channel planes [hi | lo] (hi = fp16(v), lo = fp16(v - hi)); the OPERAND a tripled-K
+    // pack multiplies is [hi | hi | lo] (against [w_hi | w_lo | w_hi] per tap) -- the gather maps operand channel c of a tap to stored channel
+    // c < x3_in ? c : c - x3_in (x3_in = the input's plane stride, 0 = not a split tensor; p.Ci stays the operand's 3 x3_in, p.Cs the stored 2 x3_in).
+    // NHWC epilogues: x3_out > 0 = the output is a split tensor -- channel n goes to n (hi) and n + x3_out (lo = v - hi); x3_res > 0 = the residual
+    // is one: value = res[n] + res[n + x3_res].  Plane strides in channels.
+    int x3_out, x3_res, x3_in;
     const float *oscale;   // DT_F16X3: [Npad] f32 or nullptr -- the accumulator of channel n is multiplied by oscale[n] in front of the bias.  The rows of a
                            // split pack are scaled by powers of two (max |w| of a row -> [2^13, 2^14)) so that w_lo stays a NORMAL fp16 number
                            // (unscaled, BN-folded weights of 1e-2 .. 1e-3 leave it subnormal: 3e-6 .. 3e-5 relative instead of 2^-22); oscale undoes it, exactly
@@ -118,7 +121,7 @@ struct SeqLayer {
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
-    static constexpr int x3_out = 0, x3_res = 0;           // (split-operand tensors never run inside a sequence)
+    static constexpr int x3_out = 0, x3_res = 0, x3_in = 0;   // (split-operand tensors never run inside a sequence)
     static constexpr const float *oscale = nullptr;
 };
 static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
@@ -336,13 +339,15 @@ struct CorrHeadParams {
 };
 int launch_corr_head(const CorrHeadParams &p, void *stream);
 
-struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; int x3; };     // x3: C logical channels stored as [hi | hi | lo] planes (3 C per pixel)
+// DT_F16X3: a split tensor is stored as X3_PLANES channel planes [hi | lo] (the operand of a tripled-K pack is [hi | hi | lo]: ConvParams::x3_in)
+constexpr int X3_PLANES = 2;
+struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; int x3; };     // x3: C channels stored as [hi | lo] planes (2 C per pixel)
 // the fused stem (stem_pool.hip): NCHW f32 frame -> conv1 7x7/2 + BN + ReLU -> p0 [B][s0][s0][64] -> maxpool 3x3/2 p1 -> x1 [B][s1][s1][64], f16
 struct StemPoolParams { const float *in; const void *wgt_frag; const float *bias; void *p0; void *x1; int B, S, s0, s1, Kpad; };
 
-struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; int x3; };  // NCHW f32 -> NHWC dtype (x3: [hi | hi | lo] planes of Cpad channels)
+struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; int x3; };  // NCHW f32 -> NHWC dtype (x3: [hi | lo] planes of Cpad channels)
 // pairs = 1 (stem input, C <= 4): [B][H][ceil(W/2)][2 pixels x 4 channels], missing pixel / channel = 0
-struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; int plane; };  // NHWC dtype -> NCHW f32 (plane > 0: split tensor, value = hi + lo at coff + 2 plane)
+struct CvtOutParams { const void *in; float *out; int B, C, H, W, Cs, coff; int plane; };  // NHWC dtype -> NCHW f32 (plane > 0: split tensor, value = hi + lo at coff + plane)
 
 // on-device restatement of the host decode of tools/test.py:205-254 (one workgroup per stream)
 struct DecodeParams {
@@ -457,8 +462,8 @@ int launch_refine_chain(const RefineChainParams &p, void *stream);
 // the chain and ONE NCHW f32 convolution (the mask head, 128x128 tiles) as one horizontally fused launch
 int launch_chain_mask(const RefineChainParams &rp, ConvBatch &cb, void *stream);
 int launch_xcorr(const XcorrParams &p, int dtype, void *stream);
-// DT_F16X3 (x3_kernels.hip): x [B][H][W][3 Cx], k [B][kh][kw][3 Cx] in whole-tensor planes (stride Cx = p.Cs), C = channels computed; out
-// [B][Ho][Wo][3 Cx] PER-BRANCH planes: logical channel c = 256 g + cc lives at 768 g + 256 plane + cc (head.0 is a grouped convolution)
+// DT_F16X3 (x3_kernels.hip): x [B][H][W][2 Cx], k [B][kh][kw][2 Cx] in whole-tensor planes [hi | lo] (stride Cx = p.Cs), C = channels computed; out
+// [B][Ho][Wo][2 Cx] PER-BRANCH planes: channel c = 256 g + cc lives at 512 g + 256 plane + cc (head.0 is a grouped convolution)
 int launch_xcorr_x3(const XcorrParams &p, void *stream);
 void xcorr_prepare();      // one-time kernel attribute set-up (large dynamic LDS); call outside stream capture
 int launch_maxpool(const PoolParams &p, int dtype, void *stream);

@@ -1,9 +1,9 @@
-// x3_kernels.hip -- the glue kernels of DT_F16X3 contexts (smk_kernels.h): values as [hi | hi | lo] fp16 channel planes.
-// The convolutions are the fp16 implicit-GEMM kernels on a tripled K (conv_igemm.hip's epilogue splits); what is here is everything
+// x3_kernels.hip -- the glue kernels of DT_F16X3 contexts (smk_kernels.h): values stored as [hi | lo] fp16 channel planes.
+// The convolutions are the fp16 implicit-GEMM kernels on a tripled K (their gathers read the hi plane twice, their epilogues split); what is here is everything
 // that is NOT a convolution on the track path: the frame -> split NHWC (tools/test.py:105-112 hands the crop over as float32), the
 // stem's max-pool (experiments/siammask_sharp/resnet.py:158), the depth-wise cross-correlation (models/rpn.py:32-38), and the read-back of
-// a split tensor for the parity tests.  All arithmetic on hi + lo in fp32; none of these is a hot kernel (the context's time is its
-// convolutions), so they are written for clarity: one thread per output value, coalesced along the channels.
+// a split tensor for the parity tests.  All arithmetic on hi + lo in fp32; eight channels (one 16-byte vector per plane) per thread, coalesced
+// along the channels.
 #include <hip/hip_runtime.h>
 #include "smk_kernels.h"
 
@@ -16,7 +16,7 @@ __device__ __forceinline__ void x3_split(const float v, _Float16 &hi, _Float16 &
 }
 }  // namespace
 
-// one thread per (pixel, octet of channels): plane-coalesced reads, three 16-byte writes
+// one thread per (pixel, octet of channels): plane-coalesced reads, two 16-byte writes
 __global__ __launch_bounds__(256) void cvt_in_x3_kernel(const CvtInParams p) {
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int oct = p.Cpad >> 3;
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void cvt_in_x3_kernel(const CvtInParams p) {
             x3_split(v, h, l);
             hi[e] = h; lo[e] = l;
         }
-        _Float16 *o = out + (size_t)pix * 3 * p.Cpad + q * 8;
-        *(half8 *)o = hi; *(half8 *)(o + p.Cpad) = hi; *(half8 *)(o + 2 * p.Cpad) = lo;
+        _Float16 *o = out + (size_t)pix * 2 * p.Cpad + q * 8;
+        *(half8 *)o = hi; *(half8 *)(o + p.Cpad) = lo;
     }
 }
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void cvt_out_x3_kernel(const CvtOutParams p) {
         const long t = idx / hw;
         const int c = (int)(t % p.C), b = (int)(t / p.C);
         const _Float16 *s = in + ((size_t)b * hw + yx) * p.Cs + p.coff + c;
-        p.out[idx] = (float)s[0] + (float)s[2 * p.plane];
+        p.out[idx] = (float)s[0] + (float)s[p.plane];
     }
 }
 
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void maxpool_x3_kernel(const PoolParams p) {
             for (int dx = 0; dx < 3; ++dx) {
                 const int ix = ox * 2 - 1 + dx;
                 if ((unsigned)ix >= (unsigned)p.W) continue;
-                const _Float16 *s = in + ((size_t)(b * p.H + iy) * p.W + ix) * 3 * p.C + c;
-                const half8 h = *(const half8 *)s, l = *(const half8 *)(s + 2 * p.C);
+                const _Float16 *s = in + ((size_t)(b * p.H + iy) * p.W + ix) * 2 * p.C + c;
+                const half8 h = *(const half8 *)s, l = *(const half8 *)(s + p.C);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float v = (float)h[e] + (float)l[e];
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void maxpool_x3_kernel(const PoolParams p) {
             x3_split(m[e], h, l);
             hi[e] = h; lo[e] = l;
         }
-        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * p.C + c;
-        *(half8 *)o = hi; *(half8 *)(o + p.C) = hi; *(half8 *)(o + 2 * p.C) = lo;
+        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 2 * p.C + c;
+        *(half8 *)o = hi; *(half8 *)(o + p.C) = lo;
     }
 }
 
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void dw_xcorr_x3_kernel(const XcorrParams p) {
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         for (int ky = 0; ky < p.kh; ++ky)
             for (int kx = 0; kx < p.kw; ++kx) {
-                const _Float16 *xs = x + ((size_t)(b * p.H + oy + ky) * p.W + ox + kx) * 3 * Cx + c;
-                const _Float16 *ks = k + ((size_t)(b * p.kh + ky) * p.kw + kx) * 3 * Cx + c;
-                const half8 xh = *(const half8 *)xs, xl = *(const half8 *)(xs + 2 * Cx);
-                const half8 kh8 = *(const half8 *)ks, kl = *(const half8 *)(ks + 2 * Cx);
+                const _Float16 *xs = x + ((size_t)(b * p.H + oy + ky) * p.W + ox + kx) * 2 * Cx + c;
+                const _Float16 *ks = k + ((size_t)(b * p.kh + ky) * p.kw + kx) * 2 * Cx + c;
+                const half8 xh = *(const half8 *)xs, xl = *(const half8 *)(xs + Cx);
+                const half8 kh8 = *(const half8 *)ks, kl = *(const half8 *)(ks + Cx);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     acc[e] = __builtin_fmaf((float)xh[e] + (float)xl[e], (float)kh8[e] + (float)kl[e], acc[e]);
@@ -131,8 +131,71 @@ __global__ __launch_bounds__(256) void dw_xcorr_x3_kernel(const XcorrParams p) {
             lo[e] = (_Float16)(acc[e] - (float)hi[e]);
         }
         const int g = c >> 8, cc = c & 255;
-        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 3 * Cx + g * 768 + cc;
-        *(half8 *)o = hi; *(half8 *)(o + 256) = hi; *(half8 *)(o + 512) = lo;
+        _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * 2 * Cx + g * 512 + cc;
+        *(half8 *)o = hi; *(half8 *)(o + 256) = lo;
+    }
+}
+
+// the same for the path's 5 x 5 template: one thread = XSEG consecutive outputs of a row x eight channels.  The XSEG + 4 search values of a
+// kernel row stay in registers and serve all five kx (28 vector loads per ky for XSEG = 5 outputs instead of 100: the one-output form above
+// spends its time re-reading the search row through the L1).  Per output the products are added in the same (ky, kx) order on the same
+// fp32 values: bit-identical to dw_xcorr_x3_kernel.
+template <int XSEG>
+__global__ __launch_bounds__(256) void dw_xcorr_x3_k5_kernel(const XcorrParams p) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    constexpr int KW = 5;
+    const int cv = p.C >> 3, nseg = (p.Wo + XSEG - 1) / XSEG;
+    const long total = (long)p.B * p.Ho * nseg * cv;
+    const _Float16 *x = (const _Float16 *)p.x, *k = (const _Float16 *)p.k;
+    _Float16 *out = (_Float16 *)p.out;
+    const int Cx = p.Cs;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) << 3;
+        long t = idx / cv;
+        const int ox0 = (int)(t % nseg) * XSEG; t /= nseg;
+        const int oy = (int)(t % p.Ho);
+        const int b = (int)(t / p.Ho);
+        float acc[XSEG][8];
+#pragma unroll
+        for (int j = 0; j < XSEG; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+        for (int ky = 0; ky < KW; ++ky) {
+            float xf[XSEG + KW - 1][8];
+            const _Float16 *xrow = x + ((size_t)(b * p.H + oy + ky) * p.W) * 2 * Cx + c;
+#pragma unroll
+            for (int j = 0; j < XSEG + KW - 1; ++j) {
+                int ix = ox0 + j;
+                ix = ix < p.W ? ix : p.W - 1;                  // (columns only a clipped output of the last segment would use)
+                const half8 h = *(const half8 *)(xrow + (size_t)ix * 2 * Cx), l = *(const half8 *)(xrow + (size_t)ix * 2 * Cx + Cx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xf[j][e] = (float)h[e] + (float)l[e];
+            }
+            const _Float16 *krow = k + ((size_t)(b * KW + ky) * KW) * 2 * Cx + c;
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const half8 h = *(const half8 *)(krow + (size_t)kx * 2 * Cx), l = *(const half8 *)(krow + (size_t)kx * 2 * Cx + Cx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float kf = (float)h[e] + (float)l[e];
+#pragma unroll
+                    for (int j = 0; j < XSEG; ++j) acc[j][e] = __builtin_fmaf(xf[j + kx][e], kf, acc[j][e]);
+                }
+            }
+        }
+        const int g = c >> 8, cc = c & 255;
+#pragma unroll
+        for (int j = 0; j < XSEG; ++j) {
+            if (ox0 + j >= p.Wo) break;
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)acc[j][e];
+                lo[e] = (_Float16)(acc[j][e] - (float)hi[e]);
+            }
+            _Float16 *o = out + ((size_t)(b * p.Ho + oy) * p.Wo + ox0 + j) * 2 * Cx + g * 512 + cc;
+            *(half8 *)o = hi; *(half8 *)(o + 256) = lo;
+        }
     }
 }
 
@@ -157,6 +220,12 @@ int launch_maxpool_x3(const PoolParams &p, void *stream) {
 }
 int launch_xcorr_x3(const XcorrParams &p, void *stream) {
     if ((p.C & 255) || p.Cs < p.C) return -1;
+    if (p.kh == 5 && p.kw == 5 && p.W >= 5) {
+        constexpr int XSEG = 5;
+        hipLaunchKernelGGL(dw_xcorr_x3_k5_kernel<XSEG>, dim3(grid_for((long)p.B * p.Ho * ((p.Wo + XSEG - 1) / XSEG) * (p.C >> 3))), dim3(256), 0,
+                           (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
     hipLaunchKernelGGL(dw_xcorr_x3_kernel, dim3(grid_for((long)p.B * p.Ho * p.Wo * (p.C >> 3))), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

@@ -1,9 +1,9 @@
 """Split-operand fp16 contexts (dtype "f16x3", SMK_DTYPE_F16X3, ABI 1.6) -- north_star: "bit-exact for the argmax box index"
 (/root/reference/tools/test.py:237 np.argmax(pscore)) at more than the fp32 matrix pipe's speed.
 
-Every value of the track path's trunk is an fp16 pair hi + lo stored as channel planes [hi | hi | lo]; the weights are packed
-[w_hi | w_lo | w_hi] per tap, so the fp16 implicit-GEMM kernel on the tripled K forms x_hi w_hi + x_hi w_lo + x_lo w_hi in its fp32
-accumulators (conv_igemm.hip's epilogue splits the result again).  The CPU model of exactly this arithmetic reproduces the fp64
+Every value of the track path's trunk is an fp16 pair hi + lo stored as two channel planes [hi | lo]; a convolution's gather presents them
+as the operand [hi | hi | lo] and the weights are packed [w_hi | w_lo | w_hi] per tap, so the fp16 implicit-GEMM kernel on the tripled K forms
+x_hi w_hi + x_hi w_lo + x_lo w_hi in its fp32 accumulators (conv_igemm.hip's epilogue splits the result again).  The CPU model of exactly this arithmetic reproduces the fp64
 oracle's index on 1024 / 1024 streams (tools/measure/cpu_split_operand_study.py, profiles/r06_cpu_split_operand_study.json); here the
 DEVICE is held to it:
   * one convolution (every geometry class of the path) against the float64 oracle at the fp32 context's gate (2e-5);
@@ -27,7 +27,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 X3_CONVS = [
     # cin, cout, k, stride, pad, dil, hw, B, with_res
-    (3, 64, 7, 2, 0, 1, 63, 2, False),        # stem: 3 -> 8 channels x 3 planes = 24 per tap (taps straddle K tiles)
+    (3, 64, 7, 2, 0, 1, 63, 2, False),        # stem: 3 -> 8 channels, operand [hi | hi | lo] = 24 per tap (taps straddle K tiles)
     (64, 64, 1, 1, 0, 1, 31, 2, False),       # layer1 1x1
     (64, 64, 3, 1, 1, 1, 31, 2, False),       # layer1 3x3
     (256, 1024, 1, 1, 0, 1, 15, 1, True),     # Bottleneck conv3 + residual + ReLU (the residual is a split tensor too)
