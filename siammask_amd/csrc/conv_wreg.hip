@@ -8,10 +8,24 @@ namespace smk {
 
 #include "wreg_tile.inc"
 
+// How far ahead the two operand streams run.  MODE 3 / 4: a 3- / 4-deep activation ring, weight fragments two K tiles ahead -- in K-STEPS
+// (16 values of K: what one consumer wave multiplies between two refills) that is 8 + 8 for the N-wide tiles (WK = 1) but only 4 + 4 for WK = 2
+// and 2 + 2 for WK = 4, because a K tile is 4 / WK steps of a wave.  The narrow tiles are the ones the path launches where M is small (B = 1:
+// every layer; Refine's window convolutions; the split-operand contexts' layer3), i.e. where a launch is ONE latency chain per wave: two steps
+// (~110 ns of MFMA) of cover against an L2 round trip.  MODE 8 (round 6) gives every shape the N-wide tiles' eight steps: ring 2 WK + 1 deep,
+// weights 2 WK tiles ahead (WK = 1: identical to MODE 3).  MEASURED SLOWER wherever the narrow tiles run (profiles/r06r_wreg_deep_prefetch.txt:
+// B = 1 step +9.6 %, B = 8 +2.5 %, f16x3 +2.9 %; the 64 x 64 launches +10..40 % each) -- like the six-deep ring of round 2
+// (profiles/r02_wreg_deep_ring.txt): these launches are not waiting for operands that were requested too late.  `make MEASURE=1` builds only.
+template <int WK, int MODE> struct WregDepth {
+    static constexpr int NSTAGE = MODE == 8 ? 2 * WK + 1 : MODE;
+    static constexpr int WT = MODE == 8 ? 2 * WK : 2;
+};
+
 // ---- one convolution (or a merged batch of independent ones) per launch ------------------------------------------
-template <int FM, int WN, int WK, int NSTAGE, int NPW>
-__global__ __launch_bounds__((WN * WK + NPW) * 64, ((NPW == 2 && WregLds<FM, NSTAGE, WN * WK>::v <= 80 * 1024) ? 2 : 1))
+template <int FM, int WN, int WK, int MODE, int NPW>
+__global__ __launch_bounds__((WN * WK + NPW) * 64, ((NPW == 2 && WregLds<FM, WregDepth<WK, MODE>::NSTAGE, WN * WK>::v <= 80 * 1024) ? 2 : 1))
 void conv_wreg_kernel(const ConvBatch cb) {
+    constexpr int NSTAGE = WregDepth<WK, MODE>::NSTAGE, WT = WregDepth<WK, MODE>::WT;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < CONV_BATCH_MAX; ++i)
@@ -28,7 +42,7 @@ void conv_wreg_kernel(const ConvBatch cb) {
         t = x * q + (x < r ? x : r) + j;
     }
     const int tm = t / tilesN, tn = t - tm * tilesN;
-    wreg_tile<FM, WN, WK, NSTAGE, 0, 2, NPW>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
+    wreg_tile<FM, WN, WK, NSTAGE, 0, WT, NPW>(p, (int)blockIdx.z, tm * BM, p.M, tn * BN, smem);
 }
 
 #ifdef SMK_MEASURE
@@ -82,10 +96,16 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
     }
 #endif
     if (g_tune.npw == 4) {
-        if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+#ifdef SMK_MEASURE
+        if (stages == 8 && WK > 1) {
+            hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, (WK > 1 ? 8 : 3), 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+#endif
+        if (stages == 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
         else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
     } else {
-        if (stages >= 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 2>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
+        if (stages == 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 2>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
         else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 2>), grid, dim3((WN * WK + 2) * 64), 0, s, cb);
     }
     return hipGetLastError() == hipSuccess ? 0 : -4;

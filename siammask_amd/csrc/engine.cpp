@@ -1391,7 +1391,15 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (p.kh == 3 && p.stride == 2 && K >= 1152 && p.Nst <= 128) return 3;
     return 0;
 }
-static int wreg_stages() { return g_tune.wreg_stages ? g_tune.wreg_stages : 3; }
+// depth of conv_wreg_kernel's activation ring: three K tiles, four in split-operand contexts (their K loops are three times as long and mostly on the
+// narrow tiles: +2.6 % on the B = 8 step, profiles/r06q_x3_ring_depth_b1_levers.txt; no gain in the fp16 contexts, HISTORY 3.1g)
+static int wreg_stages(const smk_ctx *c = nullptr) { return g_tune.wreg_stages ? g_tune.wreg_stages : ((c && c->dtype == DT_F16X3) ? 4 : 3); }
+// per-op entry points: bits 6-7 of the tile code -- 0 the library's choice, 1 eight k-steps ahead on every shape (conv_wreg.hip WregDepth; MEASURE builds,
+// otherwise the three-deep ring), 2 / 3 a 3- / 4-deep ring
+static int wreg_stages_from_code(int code) {
+    const int st = (code >> 6) & 3;
+    return st == 0 ? wreg_stages() : (st == 1 ? 8 : (st == 2 ? 3 : 4));
+}
 
 // conv_pp_kernel (conv_pp.hip: 256 x 256 tiles, two wave groups alternating between fetching and multiplying) takes the long-K
 // convolutions once 256-row tiles fill the chip in (nearly) whole rounds -- the 3x3 shortcuts and layer3's conv2 from B ~ 53 (BASELINE
@@ -1455,9 +1463,9 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
         cb.n = 1;
         cb.p[0] = p;
         char kw_[64];
-        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages());
+        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c));
         ProfScope ps(c, s, id, kw_, flop, bytes);
-        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
+        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), s);
         if (rc == 1) ps.cancel();
         else bm = 0;
     }
@@ -1538,9 +1546,9 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
             if (!wreg_choice(cb.p[i], jobs[i].o, kdtype(c->dtype))) wr = 0;
         if (wr) {
             char kw_[64];
-            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), cb.n);
+            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), cb.n);
             ProfScope ps(c, s, mid.c_str(), kw_, mflop, mbytes);
-            const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(), s);
+            const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), s);
             if (rc == 0) return 0;
             ps.cancel();
             if (rc != 1) return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
@@ -2602,7 +2610,13 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_max_batch")) { if (value < 1) return fail(SMK_E_ARG, "seq_max_batch >= 1"); g_tune.seq_max_batch = value; }
     else if (!strcmp(key, "seq_extra_batch")) g_tune.seq_extra_batch = value;
     else if (!strcmp(key, "seq_mult_max")) { if (value < 0) return fail(SMK_E_ARG, "seq_mult_max >= 0"); g_tune.seq_mult_max = value; }
-    else if (!strcmp(key, "wreg_stages")) { if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4"); g_tune.wreg_stages = value; }
+    else if (!strcmp(key, "wreg_stages")) { 
+#ifdef SMK_MEASURE
+        if (value != 0 && value != 3 && value != 4 && value != 8) return fail(SMK_E_ARG, "wreg_stages 0|3|4|8");
+#else
+        if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4 (8 = eight k-steps ahead on every tile shape: measured slower, `make MEASURE=1` builds only)");
+#endif
+        g_tune.wreg_stages = value; }
     else if (!strcmp(key, "chain")) g_tune.chain = value != 0;
     else if (!strcmp(key, "halo_db")) g_tune.halo_db = value != 0;
     else if (!strcmp(key, "ksplit")) { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(SMK_E_ARG, "ksplit 0|1|2|4"); g_tune.ksplit = value; }
@@ -3333,7 +3347,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         ConvBatch cb;
         cb.n = 1;
         cb.p[0] = p;
-        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], ((o.tile_code >> 6) & 3) == 3 ? 4 : 3, s);
+        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages_from_code(o.tile_code), s);
         if (rc == 1) return fail(SMK_E_ARG, "smk_op_conv2d_ex: geometry / dtype is not eligible for conv_wreg_kernel");
     } else if (mode == 6) {                            // conv_pp_kernel (256 x 256 tiles)
         rc = dtype == DT_F16 ? launch_conv_pp(p, s) : 1;
@@ -3700,7 +3714,7 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
         p.wgt_frag = p.wgt;                              // timing only: the fragment order is irrelevant
         if (!conv_wreg_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_wreg_kernel");
     }
-    const int wr_stages = ((o.tile_code >> 6) & 3) == 3 ? 4 : 3;
+    const int wr_stages = wreg_stages_from_code(o.tile_code);
     if (mode == 6 && !conv_pp_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_pp_kernel");
     auto launch = [&]() {
         if (mode == 6) return launch_conv_pp(p, s);

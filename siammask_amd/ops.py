@@ -29,7 +29,7 @@ def tile_code(tile=None, kt=0, stages=0):
 
 def wreg_code(tile, stages=0):
     """second byte of `algo` for algo='wreg': conv_wreg_kernel tile (bm, bn) and A-ring depth (0|3|4)"""
-    return WREG_TILE[tuple(tile)] | ({0: 0, 3: 2, 4: 3}[stages] << 6)
+    return WREG_TILE[tuple(tile)] | ({0: 0, 8: 1, 3: 2, 4: 3}[stages] << 6)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, dil=1, relu=False, res=None, res_mode=1, dtype="f32",

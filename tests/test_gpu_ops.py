@@ -274,7 +274,7 @@ WREG_CASES = [
 @pytest.mark.parametrize("cfg", WREG_CASES)
 def test_conv_wreg_kernel(cfg):
     """conv_wreg_kernel (weights in MFMA-fragment order straight into registers, activations through LDS) against the
-    oracle: every workgroup shape x both A-ring depths, bias + ReLU (+ residual), M tails, N overhang."""
+    oracle: every workgroup shape x the three prefetch depths (bit-equal among themselves), bias + ReLU (+ residual), M tails, N overhang."""
     ops = _ops()
     cin, cout, k, stride, pad, dil, hw, B, with_res = cfg
     rng = np.random.default_rng(hash(cfg) & 0xffff)
@@ -290,10 +290,14 @@ def test_conv_wreg_kernel(cfg):
     xd = torch.from_numpy(x).cuda()
     errs = {}
     for tile in WREG_TILES:
-        for stages in (3, 4):
+        ys = {}
+        for stages in (3, 4, 8):             # (8 = the measured-slower deep prefetch: its own kernels in `make MEASURE=1` builds, the 3-deep ring otherwise)
             y = ops.conv2d(xd, w, b, stride, pad, dil, relu=True, res=rd, res_mode=1, dtype="f16", algo="wreg", tile=tile,
                            stages=stages)
+            ys[stages] = y.clone()
             errs["%dx%d/s%d" % (tile[0], tile[1], stages)] = rel_err(y.cpu().numpy(), ref)
+        # how far ahead the operand streams run (ring depth, weight fragments in registers) changes no accumulator's k order
+        assert torch.equal(ys[3], ys[4]) and torch.equal(ys[3], ys[8]), (cfg, tile)
     bad = {a: e for a, e in errs.items() if not e <= TOL["f16"]}
     assert not bad, "wreg %s: %s (all: %s)" % (cfg, bad, errs)
 
