@@ -101,6 +101,12 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
             hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, (WK > 1 ? 8 : 3), 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
             return hipGetLastError() == hipSuccess ? 0 : -4;
         }
+        if (stages == 5 || stages == 6 || stages == 7) {          // deeper ACTIVATION rings only (weights two K tiles ahead as always)
+            if (stages == 5) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 5, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+            else if (stages == 6) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 6, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+            else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 7, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
 #endif
         if (stages == 4) hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 4, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);
         else hipLaunchKernelGGL((conv_wreg_kernel<FM, WN, WK, 3, 4>), grid, dim3((WN * WK + 4) * 64), 0, s, cb);

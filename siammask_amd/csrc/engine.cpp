@@ -1391,9 +1391,13 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (p.kh == 3 && p.stride == 2 && K >= 1152 && p.Nst <= 128) return 3;
     return 0;
 }
-// depth of conv_wreg_kernel's activation ring: three K tiles, four in split-operand contexts (their K loops are three times as long and mostly on the
-// narrow tiles: +2.6 % on the B = 8 step, profiles/r06q_x3_ring_depth_b1_levers.txt; no gain in the fp16 contexts, HISTORY 3.1g)
-static int wreg_stages(const smk_ctx *c = nullptr) { return g_tune.wreg_stages ? g_tune.wreg_stages : ((c && c->dtype == DT_F16X3) ? 4 : 3); }
+// depth of conv_wreg_kernel's activation ring: three K tiles; four in split-operand contexts (their K loops are three times as long and mostly on the
+// narrow tiles: +2.3 .. 2.6 % on the B = 8 step) and for one or two streams (every layer on 64 x 64 tiles: +1.8 % on the B = 1 step).  Deeper rings (5 .. 7)
+// lose everywhere, and so does running the WEIGHT stream further ahead: profiles/r06q_x3_ring_depth_b1_levers.txt, r06t_wreg_ring_depth.txt, r06r_wreg_deep_prefetch.txt
+static int wreg_stages(const smk_ctx *c = nullptr, int B = 0) {
+    if (g_tune.wreg_stages) return g_tune.wreg_stages;
+    return (c && (c->dtype == DT_F16X3 || (B >= 1 && B <= 2))) ? 4 : 3;
+}
 // per-op entry points: bits 6-7 of the tile code -- 0 the library's choice, 1 eight k-steps ahead on every shape (conv_wreg.hip WregDepth; MEASURE builds,
 // otherwise the three-deep ring), 2 / 3 a 3- / 4-deep ring
 static int wreg_stages_from_code(int code) {
@@ -1463,9 +1467,9 @@ static int run_conv(smk_ctx *c, const char *id, const Act &in, const Act *out, i
         cb.n = 1;
         cb.p[0] = p;
         char kw_[64];
-        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c));
+        snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c, B));
         ProfScope ps(c, s, id, kw_, flop, bytes);
-        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), s);
+        rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c, B), s);
         if (rc == 1) ps.cancel();
         else bm = 0;
     }
@@ -1546,9 +1550,9 @@ static int run_conv_jobs(smk_ctx *c, const std::vector<ConvJob> &jobs, int B, in
             if (!wreg_choice(cb.p[i], jobs[i].o, kdtype(c->dtype))) wr = 0;
         if (wr) {
             char kw_[64];
-            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), cb.n);
+            snprintf(kw_, sizeof(kw_), "conv_wreg<%s,%dx%d,s%d,merged%d>", dtname(kdtype(c->dtype)), WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c, B), cb.n);
             ProfScope ps(c, s, mid.c_str(), kw_, mflop, mbytes);
-            const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c), s);
+            const int rc = launch_conv_wreg_batch(cb, WREG_TILE[wr][0], WREG_TILE[wr][1], wreg_stages(c, B), s);
             if (rc == 0) return 0;
             ps.cancel();
             if (rc != 1) return fail(SMK_E_HIP, "launch of merged conv %s.. failed: %s", jobs[0].id, hipGetErrorString(hipGetLastError()));
@@ -2612,7 +2616,7 @@ int smk_tune(const char *key, int value) {
     else if (!strcmp(key, "seq_mult_max")) { if (value < 0) return fail(SMK_E_ARG, "seq_mult_max >= 0"); g_tune.seq_mult_max = value; }
     else if (!strcmp(key, "wreg_stages")) { 
 #ifdef SMK_MEASURE
-        if (value != 0 && value != 3 && value != 4 && value != 8) return fail(SMK_E_ARG, "wreg_stages 0|3|4|8");
+        if (value != 0 && (value < 3 || value > 8)) return fail(SMK_E_ARG, "wreg_stages 0|3..8");
 #else
         if (value != 0 && value != 3 && value != 4) return fail(SMK_E_ARG, "wreg_stages 0|3|4 (8 = eight k-steps ahead on every tile shape: measured slower, `make MEASURE=1` builds only)");
 #endif
