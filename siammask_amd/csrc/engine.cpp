@@ -333,7 +333,7 @@ struct smk_ctx {
     int ring_batch = 0;              // batch the result ring was sized for (smk_set_result_ring)
     bool pipe_tail_has_mask = false; // (A/B knob pipe_eager bit 1) mid's capture handed the mask head to the tail
     unsigned *pipe_cnt = nullptr;    // device [16] u32: [0] semaphore "tails completed" (starts at 1), [2] semaphore "main parts completed",
-                                     // [4] / [5] arrival counters of decode's streams / chain_mask's workgroups (misc_kernels.hip pipe_*)
+                                     // [4] / [5] arrival counters of decode's streams / chain_mask's workgroups, [8] "this step's main part is running" (arms the tail gate's clock; misc_kernels.hip pipe_*)
     bool pipe_two = false;           // (recording a depth-2 pipelined step) decode keeps its own ring cursor
     bool pipe_corr_sem = false;      // ... or corr_head's first workgroup does (form 2)
     bool pipe_seq_exit = false, pipe_seq_exit_done = false;   // ... and the sequence launch raises the "chip is free" semaphore when it leaves
@@ -1847,7 +1847,7 @@ static int seq_track(smk_ctx *c, const float *x, int B, int flags, float *cls, f
         // pipelined step without the persistent sequence: nothing up to here writes what the previous frame's tail reads (p0 / p1 / p2
         // exist twice), so the gate sits HERE -- the tail has the whole backbone of this frame to finish beside -- and the heads below
         // (corr, head0, the decoded position) are the first writers it protects
-        if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, s)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, s, 0, nullptr, c->pipe_cnt + 8)) return fail(SMK_E_HIP, "pipe_gate launch failed");
         c->cap_has_seq = true;
     }
     Act corr = act(c, "corr", 25, 25, X(256 * nbt));
@@ -2915,7 +2915,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     auto main_ = [&](hipStream_t st) {
         CHK(front(st));
         if (!late) {
-            if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+            if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st, 0, nullptr, c->pipe_cnt + 8)) return fail(SMK_E_HIP, "pipe_gate launch failed");
             c->cap_has_seq = true;          // (the gate reports through the sequence failure flag: checked like a sequence launch)
         }
         c->pipe_gate_late = late;           // ... else seq_track places it in front of the heads
@@ -2938,7 +2938,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     };
     // part: 0 = the whole tail (depth 1), 1 / 2 = its two parts (depth 2); gated: with the gate at its head
     auto tail = [&](hipStream_t st, int part, bool gated) {
-        if (gated && tgate && launch_pipe_gate(c->pipe_cnt + (part == 2 ? 7 : 2), c->seq_err, c->seq_err_hdev, st, 1)) return fail(SMK_E_HIP, "pipe_gate launch failed");
+        if (gated && tgate && launch_pipe_gate(c->pipe_cnt + (part == 2 ? 7 : 2), c->seq_err, c->seq_err_hdev, st, 1, part == 2 ? nullptr : c->pipe_cnt + 8)) return fail(SMK_E_HIP, "pipe_gate launch failed");
         c->pipe_tail_fold = gate && part == 0;      // a whole tail that ends in chain_mask_kernel lets its last workgroup be the "done" mark
         c->pipe_done_folded = false;
         const int rct = step_tail(c, B, mask, box_out, refine_out, st, part);

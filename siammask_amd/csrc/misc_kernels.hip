@@ -662,24 +662,38 @@ __global__ __launch_bounds__(256) void ring_commit_kernel(const RingParams p) {
 // `limit` (100 MHz ticks): the MAIN gate waits for a tail that was enqueued on a free side stream a frame ago -- bounded by the tail's own
 // run time, 0.2 s is generous.  A gate at the head of a TAIL starts polling as soon as the side stream is free, i.e. possibly long before
 // the step it belongs to even starts on the caller's stream (whatever the caller enqueued in front of the step runs first): its limit is
-// 5 s -- long enough for any sane stream, short enough that a lost partner never hangs the device for good.
-__device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host, unsigned long long limit) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+// 5 s -- and (round 6) those 5 s only start once the step's MAIN part is known to be running: the main gate raises `started`
+// (cnt[8]) when it has passed, the tail's gate arms its clock when it sees that and lowers the word again when it passes (the next main gate
+// cannot raise it earlier: it waits for this tail's END).  A caller's stream that is blocked in front of the step for longer than 5 s -- a
+// collective waiting for a straggler rank, a host-fed event, a large copy -- therefore no longer makes the gate give the frame up; an unarmed
+// gate still gives up after two minutes, so that a lost partner never hangs the device for good.
+__device__ __forceinline__ void pipe_sem_p(unsigned *sem, int *err, int *err_host, unsigned long long limit, unsigned *started_wait = nullptr,
+                                           unsigned *started_set = nullptr) {
+    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    bool armed = started_wait == nullptr;
     while (__hip_atomic_load(sem, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!armed && __hip_atomic_load(started_wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            armed = true;
+            t0 = now;
+        }
+        if (now - t0 > (armed ? limit : 12000000000ull)) {                   // (unarmed: 120 s at 100 MHz)
             __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return;                                                          // (the count is left alone: the host resets it)
+            return;                                                          // (the counts are left alone: the host resets them)
         }
     }
     __hip_atomic_fetch_sub(sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (started_wait) __hip_atomic_store(started_wait, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (started_set) __hip_atomic_store(started_set, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // one wave, 8 VGPRs, no LDS: a gate that polls THROUGH another stream's kernels (the tail's gate is resident while the next frame's
 // persistent launch runs) must fit beside a conv_seq_kernel workgroup -- 2 x 248 of a SIMD's 512 VGPRs.  If it ever did not, the
 // persistent launch would not get its CU, decode would never run, and the gates' 0.2 s limits raise the failure flag (loud, no hang).
-__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *sem, int *err, int *err_host, unsigned long long limit) {
-    if (threadIdx.x == 0) pipe_sem_p(sem, err, err_host, limit);
+__global__ __launch_bounds__(64) void pipe_gate_kernel(unsigned *sem, int *err, int *err_host, unsigned long long limit, unsigned *started_wait,
+                                                        unsigned *started_set) {
+    if (threadIdx.x == 0) pipe_sem_p(sem, err, err_host, limit, started_wait, started_set);
 }
 __global__ __launch_bounds__(64) void pipe_done_kernel(unsigned *sem) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(sem, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -693,9 +707,9 @@ int launch_pipe_mark(unsigned *sig, void *stream) {
     hipLaunchKernelGGL(pipe_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sig);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream, int long_wait) {
+int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream, int long_wait, unsigned *started_wait, unsigned *started_set) {
     hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sem, err, err_host,
-                       long_wait ? 500000000ull : 20000000ull);             // 5 s / 0.2 s at 100 MHz
+                       long_wait ? 500000000ull : 20000000ull, started_wait, started_set);             // 5 s / 0.2 s at 100 MHz
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_pipe_done(unsigned *sem, void *stream) {

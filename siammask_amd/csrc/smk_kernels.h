@@ -486,7 +486,8 @@ int launch_maxpool_x3(const PoolParams &p, void *stream);
 int launch_decode(const DecodeParams &p, void *stream);
 int launch_ring_commit(const RingParams &p, void *stream);
 // pipelined frame steps: in-stream gate (waits for the previous frame's tail) / the tail's completion mark; cnt = device [2] u32
-int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream, int long_wait = 0);     // P: poll until *sem > 0, take one; gives up after 0.2 s (5 s)
+// P: poll until *sem > 0, take one; gives up after 0.2 s (long_wait: 5 s, counted from the moment *started_wait is non-zero); then *started_wait = 0, *started_set = 1
+int launch_pipe_gate(unsigned *sem, int *err, int *err_host, void *stream, int long_wait = 0, unsigned *started_wait = nullptr, unsigned *started_set = nullptr);
 int launch_pipe_done(unsigned *sem, void *stream);                             // V
 int launch_pipe_mark(unsigned *sig, void *stream);          // sig: signal memory (hipMallocSignalMemory), waited for with hipStreamWaitValue32
 int launch_crop_resize(const CropParams &p, int B, void *stream);
