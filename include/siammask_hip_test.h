@@ -102,8 +102,8 @@ typedef struct smk_conv_geom {
 
 /* algo: low byte 0 = MFMA kernel, NHWC epilogue; 1 = naive kernel, NHWC epilogue;
  *                2 = MFMA kernel, NCHW-f32 epilogue; 3 = naive kernel, NCHW-f32 epilogue;
- *                4 = conv3x3_halo_kernel (tile code 1 = 128 rows, else 64); 5 = conv_wreg_kernel (tile code 1..6 =
- *                64x256 64x128 64x64 128x256 128x128 128x64; ring-depth bits: 0 the library's choice, 1 eight k-steps ahead on every shape (measurement builds; else = 2), 2 / 3 = a three- / four-deep ring); 6 = conv_pp_kernel
+ *                4 = conv3x3_halo_kernel (tile code 1 = 128 rows, else 64); 5 = conv_wreg_kernel (tile code 1..8 =
+ *                64x256 64x128 64x64 128x256 128x128 128x64 96x256 32x64; ring-depth bits: 0 the library's choice, 1 eight k-steps ahead on every shape (measurement builds; else = 2), 2 / 3 = a three- / four-deep ring); 6 = conv_pp_kernel
  *                (256 x 256 tiles, fp16 only, conv_pp.hip);
  *       second byte: bits 0-3 tile override 0 auto, 1 128x128, 2 128x64, 3 64x128, 4 64x64, 5 256x128;
  *                    bits 4-5 K tile 0 auto, 1 = 128 B, 2 = 256 B; bits 6-7 LDS ring depth

@@ -128,7 +128,9 @@ int launch_conv_wreg_batch(ConvBatch &cb, int bm, int bn, int stages, void *stre
     if (cb.n < 1 || cb.n > CONV_BATCH_MAX) return -1;
     for (int i = 0; i < cb.n; ++i)
         if (!conv_wreg_eligible(cb.p[i], DT_F16) || (cb.p[i].groups > 1) != (cb.p[0].groups > 1)) return 1;
-    if (bm == 64) {
+    if (bm == 32) {
+        if (bn == 64) return launch_wreg_t<1, 1, 4>(cb, stages, s);      // (under-filled launches: twice the workgroups, half the activation rows each)
+    } else if (bm == 64) {
         if (bn == 256) return launch_wreg_t<2, 4, 1>(cb, stages, s);
         if (bn == 128) return launch_wreg_t<2, 2, 2>(cb, stages, s);
         if (bn == 64) return launch_wreg_t<2, 1, 4>(cb, stages, s);

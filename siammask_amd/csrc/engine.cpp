@@ -1340,7 +1340,7 @@ static long device_cus() {
     }
     return cached[dev];
 }
-static const int WREG_TILE[8][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}, {96, 256}};
+static const int WREG_TILE[9][2] = {{0, 0}, {64, 256}, {64, 128}, {64, 64}, {128, 256}, {128, 128}, {128, 64}, {96, 256}, {32, 64}};
 static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
     if (o.algo_naive || !conv_wreg_eligible(p, dtype)) return 0;
     if (o.wreg) return o.wreg;
@@ -1381,6 +1381,9 @@ static int wreg_choice(const ConvParams &p, const ConvOpt &o, int dtype) {
                 return cand[ci];
             }
         }
+        // nothing fills the chip: 64 x 64 -- or 32 x 64 (code 8, smk_tune "wreg32") while even that leaves CUs idle: the narrow tiles' K loops wait for
+        // their activation refills (profiles/r06t_wreg_ring_depth.txt), and a 32-row workgroup asks for half of them
+        if (g_tune.wreg32 && (long)((p.M + 63) / 64) * ((p.Nst + 63) / 64) * ng < g_tune.wreg32) return 8;
         return 3;
     }
     if (p.M < 4096) return 0;                  // not measured below B ~ 5: keep the fitted LDS-staged choice
@@ -2646,6 +2649,7 @@ int smk_tune(const char *key, int value) {
     }
 #endif
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "wreg32")) { if (value < 0 || value > 4096) return fail(SMK_E_ARG, "wreg32 0..4096 (64x64 tile count below which 32x64 tiles are used)"); g_tune.wreg32 = value; }
     else if (!strcmp(key, "front_occ1")) {
 #ifdef SMK_MEASURE
         g_tune.front_occ1 = value & 3;
@@ -2684,7 +2688,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -3347,7 +3351,7 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
     int rc;
     if (mode == 5) {                                   // conv_wreg_kernel, tile code 1..6 in the low tile bits
         const int wr = o.tile_code & 15;
-        if (wr < 1 || wr > 6) return fail(SMK_E_ARG, "smk_op_conv2d_ex: wreg tile code 1..6");
+        if (wr < 1 || wr > 8) return fail(SMK_E_ARG, "smk_op_conv2d_ex: wreg tile code 1..8");
         ConvBatch cb;
         cb.n = 1;
         cb.p[0] = p;
@@ -3714,7 +3718,7 @@ int smk_bench_conv(int dtype, int algo, const smk_conv_geom *g, int with_res, in
     const int halo_bm = mode == 4 ? ((o.tile_code & 15) == 1 ? 128 : 64) : 0;     // timing only: K order is irrelevant
     const int wr = mode == 5 ? (o.tile_code & 15) : 0;
     if (mode == 5) {
-        if (wr < 1 || wr > 6) return fail(SMK_E_ARG, "smk_bench_conv: wreg tile code 1..6");
+        if (wr < 1 || wr > 8) return fail(SMK_E_ARG, "smk_bench_conv: wreg tile code 1..8");
         p.wgt_frag = p.wgt;                              // timing only: the fragment order is irrelevant
         if (!conv_wreg_eligible(p, dtype)) return fail(SMK_E_ARG, "smk_bench_conv: not eligible for conv_wreg_kernel");
     }

@@ -247,6 +247,8 @@ struct Tuning {
     int front_occ1 = 0;        // MEASURE builds: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
                                // step's tail run BESIDE the next frame's front end then?  No: +3.5 % per step (profiles/r06g_front_occupancy_ab.txt)
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
+    int wreg32 = 140;          // conv_wreg tile choice: 32 x 64 tiles where fewer than this many 64 x 64 tiles exist (0 = never): -8..15 % per under-filled
+                               // launch, -2 % on the B = 1 step (profiles/r06w_wreg_32_row_tiles.txt)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
                                // frame), 0 = a cross-queue event wait (three graphs; measured 15-22 us of latency on the critical path)
     int pipe_two_form = 1;     // depth-2 pipelining: 1 = the mask head as its own launch at the head of the tail's first part, the bare Refine chain beside

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 ALGO = {"mfma": 0, "naive": 1, "mfma_nchw": 2, "naive_nchw": 3, "halo": 4, "wreg": 5, "pp": 6}
-WREG_TILE = {(64, 256): 1, (64, 128): 2, (64, 64): 3, (128, 256): 4, (128, 128): 5, (128, 64): 6}
+WREG_TILE = {(64, 256): 1, (64, 128): 2, (64, 64): 3, (128, 256): 4, (128, 128): 5, (128, 64): 6, (96, 256): 7, (32, 64): 8}
 TILE = {None: 0, "auto": 0, (128, 128): 1, (128, 64): 2, (64, 128): 3, (64, 64): 4, (256, 128): 5}
 
 

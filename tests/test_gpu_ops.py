@@ -256,7 +256,7 @@ def test_maxpool(dtype):
         assert y.shape == ref.shape and rel_err(y, ref) == 0.0   # max is exact
 
 
-WREG_TILES = ((64, 256), (64, 128), (64, 64), (128, 256), (128, 128), (128, 64))
+WREG_TILES = ((64, 256), (64, 128), (64, 64), (128, 256), (128, 128), (128, 64), (96, 256), (32, 64))
 WREG_CASES = [
     # cin, cout, k, stride, pad, dil, hw, B, residual
     (64, 64, 1, 1, 0, 1, 31, 2, False),      # short K (one 128-element pad: two K tiles)

@@ -229,11 +229,13 @@ def test_layer_rules_are_the_measured_ones():
     assert _plan(8, 64, 63, 256, 1, res=True)[:2] == ("igemm", (128, 128))     # l1.c3: large M, short K
     assert _plan(8, 256, 63, 64, 1)[0] == "igemm"                              # l1.c1
     assert _plan(8, 3, 255, 64, 7, stride=2)[0] == "igemm"                     # stem
-    assert _plan(8, 512, 31, 128, 3, pad=1, win=15)[:2] == ("wreg", (64, 64))  # Refine v2.0 on its own
-    # B = 1: almost everything on the register-fed kernel, 64x64 tiles
-    for args in ((1024, 31, 256, 1), (256, 31, 1024, 1), (512, 31, 128, 1), (256, 63, 64, 1)):
-        assert _plan(1, *args)[:2] == ("wreg", (64, 64)), args
-    assert _plan(1, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (64, 64))   # l3.c2
+    assert _plan(8, 512, 31, 128, 3, pad=1, win=15)[:2] == ("wreg", (32, 64))  # Refine v2.0 on its own: 58 tiles of 64 rows -> 114 of 32 (round 6, wreg32)
+    # B = 1: almost everything on the register-fed kernel, 64x64 tiles -- 32x64 (round 6, profiles/r06w_wreg_32_row_tiles.txt) where fewer than 140 of those exist
+    for args, tile in (((1024, 31, 256, 1), (32, 64)), ((256, 31, 1024, 1), (64, 64)), ((512, 31, 128, 1), (32, 64)), ((256, 63, 64, 1), (32, 64))):
+        assert _plan(1, *args)[:2] == ("wreg", tile), args
+    assert _plan(1, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (32, 64))   # l3.c2: 64 tiles of 64 rows
+    assert _plan(2, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (32, 64))   # ... 124 at B = 2
+    assert _plan(3, 256, 31, 256, 3, pad=2, dil=2)[:2] == ("wreg", (64, 64))   # ... 184 at B = 3
     assert _plan(1, 128, 31, 128, 3, pad=1)[0] == "halo"                       # l2.c2 (K = 1152)
     # B = 64: wide / long-K layers on 128x256 register-fed tiles, narrow short-K ones on LDS-staged 128-row tiles
     assert _plan(64, 1024, 31, 256, 1)[:2] == ("wreg", (128, 256))             # l3.c1
