@@ -1970,8 +1970,8 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0
     if (merged && part != 2) {
         // the window convs only depend on the kept backbone features and pos: one launch with deconv
         w2.tile_code = 4;     // 64x64 (256-byte K tile): v2.0's long K chain sets the pace
-        // smk_tune "rf_wreg": bit 0 the four members on the register-fed kernel, bits 4..6 its tile code (0 = 3: 64x64; 6 = 128x64)
-        if (g_tune.rf_wreg & 1) w2.wreg = w1.wreg = w0.wreg = od.wreg = ((g_tune.rf_wreg >> 4) & 7) ? ((g_tune.rf_wreg >> 4) & 7) : 3;
+        // smk_tune "rf_wreg": bit 0 the four members on the register-fed kernel, bits 4..7 its tile code (0 = 3: 64x64; 6 = 128x64; 8 = 32x64)
+        if (g_tune.rf_wreg & 1) w2.wreg = w1.wreg = w0.wreg = od.wreg = ((g_tune.rf_wreg >> 4) & 15) ? ((g_tune.rf_wreg >> 4) & 15) : 3;
         CHK(run_conv_jobs(c, {{"v2.0", &p2, &v2a, w2}, {"v1.0", &p1, &v1a, w1}, {"v0.0", &p0, &v0a, w0},
                               {"deconv", &corr, &d1, od}}, B, 0, s));
     } else if (part != 2) {
@@ -1990,7 +1990,7 @@ static int seq_refine(smk_ctx *c, int B, float *out, hipStream_t s, int part = 0
         ConvOpt r3l = r3;
         r3l.tile_code = g_tune.rf_tile2;          // (A/B knob: workgroup tile of the merged v*.2 launch; 0 = the lead's own choice, 64x64)
         ConvOpt r3w = r3;
-        if ((g_tune.rf_wreg & 2) && merged) r3l.wreg = r3w.wreg = ((g_tune.rf_wreg >> 8) & 7) ? ((g_tune.rf_wreg >> 8) & 7) : 3;      // bit 1: the v*.2 launch, bits 8..10 its tile code
+        if ((g_tune.rf_wreg & 2) && merged) r3l.wreg = r3w.wreg = ((g_tune.rf_wreg >> 8) & 15) ? ((g_tune.rf_wreg >> 8) & 15) : 3;      // bit 1: the v*.2 launch, bits 8..11 its tile code
         if (part != 2) CHK(run_conv_jobs(c, {{"v2.2", &v2a, &V2, r3l}, {"v1.2", &v1a, &V1, r3w}, {"v0.2", &v0a, &V0, r3w}}, B, 0, s));
         if (part == 1) return 0;
         static const char *ids[9] = {"h2.0", "h2.2", "post0", "h1.0", "h1.2", "post1", "h0.0", "h0.2", "post2"};
