@@ -2649,6 +2649,13 @@ int smk_tune(const char *key, int value) {
     }
 #endif
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "pipe_prio")) {
+#ifndef SMK_MEASURE
+        if (value != 0) return fail(SMK_E_ARG, "pipe_prio: measured slower in both directions; only in a library built with `make MEASURE=1`");
+#endif
+        if (value < 0 || value > 2) return fail(SMK_E_ARG, "pipe_prio 0|1|2");
+        g_tune.pipe_prio = value;
+    }
     else if (!strcmp(key, "wreg32")) { if (value < 0 || value > 4096) return fail(SMK_E_ARG, "wreg32 0..4096 (64x64 tile count below which 32x64 tiles are used)"); g_tune.wreg32 = value; }
     else if (!strcmp(key, "front_occ1")) {
 #ifdef SMK_MEASURE
@@ -2688,7 +2695,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_prio", &g_tune.pipe_prio}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -3095,7 +3102,18 @@ int smk_set_pipeline(smk_ctx *c, int depth) {
         if (depth >= 2 && !c->buf.count("head0#1")) CHK(alloc_buf(c, "head0#1", c->buf_elems.at("head0")));
         // (the box rows' own cursor of depth 2 starts where the shared one stands)
         if (c->ring_cursor) HIPCHK(hipMemcpy(c->ring_cursor + 2, c->ring_cursor, sizeof(int), hipMemcpyDeviceToDevice));
-        if (!c->pipe_stream) HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+        if (!c->pipe_stream) {
+            // A queue priority for the side stream (lowest: the tail's workgroups dispatched behind the next frame's front end) was measured in round 6
+            // (profiles/r06z_side_stream_priority.txt): ANY priority other than the default -- lowest or highest -- costs +50 % per B = 8 step and x4.4 at
+            // B = 1; queues of unequal priority are not arbitrated workgroup by workgroup.  The arm lives in `make MEASURE=1` builds (smk_tune pipe_prio).
+#ifdef SMK_MEASURE
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // (numerically: lo >= hi, lower value = higher priority)
+            if (g_tune.pipe_prio) HIPCHK(hipStreamCreateWithPriority(&c->pipe_stream, hipStreamNonBlocking, g_tune.pipe_prio == 1 ? lo : hi));
+            else
+#endif
+            HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+        }
         if (!c->pipe_cnt) HIPCHK(hipMalloc((void **)&c->pipe_cnt, 64));
         if (!c->pipe_sig) {
             int can = 0;

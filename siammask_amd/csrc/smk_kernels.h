@@ -254,6 +254,7 @@ struct Tuning {
     int pipe_two_form = 1;     // depth-2 pipelining: 1 = the mask head as its own launch at the head of the tail's first part, the bare Refine chain beside
                                // the next frame's heads; 0 = chain + mask head as one launch beside the heads (measured: it starves conv_search);
                                // 2 = chain + mask head as one launch behind conv_search (beside corr_head + decode: 136-216 idle CUs)
+    int pipe_prio = 0;         // (MEASURE builds) queue priority of the pipelined step's side stream (0 default, 1 lowest, 2 highest): read when the stream is created
     int pipe_late = 1;         // pipelined frame step outside the persistent sequence's batches: the main gate in front of the heads instead of in front of
                                // layer2 (the tail overlaps the whole backbone of the next frame; p2 exists twice as well)
     int pipe_sig = 2;          // pipelined frame step, how the side stream learns that decode(f) is done: 2 (default) = a one-wave gate kernel at the head of
