@@ -72,6 +72,14 @@ static int launch_wreg_t(ConvBatch &cb, int stages, hipStream_t s) {
         total += ((p.M + BM - 1) / BM) * ((p.Nst + BN - 1) / BN);
         if (p.groups > groups) groups = p.groups;
         p.ksplit = 1;
+        if (p.x3_ct > 0 && p.x3_in > 0) {
+            // split-operand pack in fused order (wreg_tile.inc x3ct): the producers gather the STORED channels [hi | lo] of a tap -- a plain fp16 gather over 2 C
+            p.Ci = p.x3_in * X3_PLANES;
+            p.ci_shift = -1;
+            for (int sh = 0; sh < 16; ++sh)
+                if ((1 << sh) == p.Ci) p.ci_shift = sh;
+            p.x3_in = 0;
+        }
     }
     for (int i = cb.n; i <= CONV_BATCH_MAX; ++i) cb.start[i] = total;
     dim3 grid(total, 1, groups);

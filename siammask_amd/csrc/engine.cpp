@@ -108,6 +108,7 @@ struct PackedConv {
     int kw = 0;              // horizontal taps when != k (pixel-pair stem)
     int alg_k = 0;           // algorithmic K (real multiply-accumulates per output) when the pack pads K
     float *oscale = nullptr; // DT_F16X3: device [rows] f32, the inverse of the power-of-two scale each row of the split pack carries (ConvParams::oscale)
+    int x3_ct = 0, x3_nreal = 0;   // DT_F16X3, w_frag in FUSED order (ConvParams::x3_ct): channels / 64, activation tiles per K loop
     bool x3 = false;         // DT_F16X3: K tripled -- per tap [w_hi | w_lo | w_hi] against the operand [hi | hi | lo] gathered from the stored planes [hi | lo]; Ci = 3 x channels
 };
 
@@ -179,7 +180,7 @@ static int upload_frag_pack(PackedConv &pc, const std::vector<float> &rows_f32, 
 }
 
 static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, const std::vector<float> &bias,
-                         int dtype) {
+                         int dtype, const std::vector<float> *frag_rows = nullptr) {
     const size_t n = rows_f32.size();
     HIPCHK(hipMalloc(&pc.w, n * esize(dtype)));
     if (dtype == DT_F16) {
@@ -191,7 +192,7 @@ static int upload_packed(PackedConv &pc, const std::vector<float> &rows_f32, con
     }
     HIPCHK(hipMalloc((void **)&pc.bias, bias.size() * 4));
     HIPCHK(hipMemcpy(pc.bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-    return upload_frag_pack(pc, rows_f32, dtype);       // derived copy for conv_wreg_kernel (f16 only)
+    return upload_frag_pack(pc, frag_rows ? *frag_rows : rows_f32, dtype);       // derived copy for conv_wreg_kernel (f16 only)
 }
 
 // chunk-major copy of a 3x3 pack: k = (tap*Ci + c)  ->  k' = ((c / CH)*9 + tap)*CH + c % CH
@@ -439,6 +440,34 @@ static void split_rows_x3(std::vector<float> &rows, int nrows, int Kpad1, int Kp
     }
     rows.swap(out);
 }
+// FUSED order of a split pack for conv_wreg_kernel (wreg_tile.inc x3ct): per tap the 3 CT tiles of 64 weights [w_hi_0 .. | w_lo_0 .. | w_hi_0 ..] become
+// (w_hi_0, w_lo_0, w_hi_1, w_lo_1, .., w_hi_{CT-1}, w_lo_{CT-1}, then w_hi_0 .. w_hi_{CT-1} for the lo plane): the two products of a hi activation tile are neighbours
+// in the weight stream.  Needs Ci0 % 64 == 0.  Sets pc.x3_ct / pc.x3_nreal; returns false (and leaves `out` alone) when the pack cannot be fused.
+static bool fuse_rows_x3(const std::vector<float> &rows, PackedConv &pc, int taps, int Ci0, std::vector<float> &out) {
+    if (Ci0 < 64 || Ci0 % 64) return false;
+    const int CT = Ci0 / 64, Kp = pc.Kpad;
+    out.assign(rows.size(), 0.f);
+    for (int n = 0; n < pc.rows; ++n) {
+        const float *s = rows.data() + (size_t)n * Kp;
+        float *d = out.data() + (size_t)n * Kp;
+        for (int t = 0; t < taps; ++t) {
+            const float *st = s + (size_t)t * 3 * Ci0;
+            float *dt = d + (size_t)t * 3 * Ci0;
+            for (int j = 0; j < CT; ++j) {
+                memcpy(dt + (size_t)(2 * j) * 64, st + (size_t)j * 64, 64 * sizeof(float));                       // w_hi_j   (x hi_j)
+                memcpy(dt + (size_t)(2 * j + 1) * 64, st + (size_t)Ci0 + (size_t)j * 64, 64 * sizeof(float));     // w_lo_j   (x hi_j again)
+                memcpy(dt + (size_t)(2 * CT + j) * 64, st + (size_t)2 * Ci0 + (size_t)j * 64, 64 * sizeof(float)); // w_hi_j   (x lo_j)
+            }
+        }
+    }
+    pc.x3_ct = CT;
+    pc.x3_nreal = 0;
+    for (int w = 0; w < Kp / 64; ++w) {
+        const int r = w % (3 * CT);
+        if (!(r < 2 * CT && (r & 1))) ++pc.x3_nreal;       // (the same cyclic rule the consumers apply, K padding included)
+    }
+    return true;
+}
 static int upload_oscale(PackedConv &pc, const std::vector<float> &oscale) {
     HIPCHK(hipMalloc((void **)&pc.oscale, oscale.size() * 4));
     HIPCHK(hipMemcpy(pc.oscale, oscale.data(), oscale.size() * 4, hipMemcpyHostToDevice));
@@ -484,6 +513,12 @@ static int pack_conv(smk_ctx *c, const std::string &id, const std::vector<ConvPa
         std::vector<float> osc;
         split_rows_x3(rows, pc.rows, K1, pc.Kpad, k * k, Ci0, osc);
         CHK(upload_oscale(pc, osc));
+        std::vector<float> fused;
+        if (g_tune.x3_fused && fuse_rows_x3(rows, pc, k * k, Ci0, fused)) {
+            CHK(upload_packed(pc, rows, bias, kdtype(c->dtype), &fused));
+            c->conv[id] = pc;
+            return 0;
+        }
     }
     CHK(upload_packed(pc, rows, bias, kdtype(c->dtype)));
     if (!grouped && !x3) CHK(upload_halo_pack(pc, rows, kdtype(c->dtype)));
@@ -750,6 +785,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     p.Hs = in.H; p.Ws = in.W; p.Cs = in.C;
     p.cin_off = o.cin_off;
     p.Ci = pc.Ci;
+    p.x3_ct = pc.x3_ct; p.x3_nreal = pc.x3_nreal;
     p.x3_in = pc.x3 ? pc.Ci / 3 : 0;      // split tensor in: the operand's [hi | hi | lo] channels of a tap are gathered from the stored [hi | lo] planes
     p.Hl = (o.win || o.ups) ? o.Hl : in.H;
     p.Wl = (o.win || o.ups) ? o.Wl : in.W;
@@ -2649,6 +2685,7 @@ int smk_tune(const char *key, int value) {
     }
 #endif
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "x3_fused")) g_tune.x3_fused = value != 0;          // (read when a split-operand context packs its weights)
     else if (!strcmp(key, "pipe_prio")) {
 #ifndef SMK_MEASURE
         if (value != 0) return fail(SMK_E_ARG, "pipe_prio: measured slower in both directions; only in a library built with `make MEASURE=1`");
@@ -2695,7 +2732,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"pipe_prio", &g_tune.pipe_prio}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"x3_fused", &g_tune.x3_fused}, {"pipe_prio", &g_tune.pipe_prio}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -3317,6 +3354,9 @@ int smk_op_conv2d_ex(int dtype, int algo, const smk_conv_geom *g, const float *x
         CHK(upload_oscale(pc, osc));
         in.C *= X3_PLANES;
     }
+    std::vector<float> fused;
+    if (x3 && g_tune.x3_fused && fuse_rows_x3(rows, pc, g->k * g->k, pc.Ci / 3, fused)) CHK(upload_packed(pc, rows, bias, dtype, &fused));
+    else
     CHK(upload_packed(pc, rows, bias, dtype));
     TmpBufs tmp;
     tmp.v.push_back(pc.w); tmp.v.push_back(pc.bias);

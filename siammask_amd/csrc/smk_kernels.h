@@ -76,6 +76,10 @@ struct ConvParams {
     // NHWC epilogues: x3_out > 0 = the output is a split tensor -- channel n goes to n (hi) and n + x3_out (lo = v - hi); x3_res > 0 = the residual
     // is one: value = res[n] + res[n + x3_res].  Plane strides in channels.
     int x3_out, x3_res, x3_in;
+    // conv_wreg_kernel on a pack in FUSED order (wreg_tile.inc): x3_ct = C / 64 > 0 -- the fragment pack's weight tiles per tap are (w_hi_0, w_lo_0, w_hi_1, ..,
+    // w_hi_0 .. for the lo plane), the activation gather is a plain one over the stored 2 C channels (the host hands the kernel Ci = 2 C, x3_in = 0: conv_wreg.hip
+    // launch_wreg_t); x3_nreal = activation tiles the producers fetch (weight tiles that do not re-use their predecessor's)
+    int x3_ct, x3_nreal;
     const float *oscale;   // DT_F16X3: [Npad] f32 or nullptr -- the accumulator of channel n is multiplied by oscale[n] in front of the bias.  The rows of a
                            // split pack are scaled by powers of two (max |w| of a row -> [2^13, 2^14)) so that w_lo stays a NORMAL fp16 number
                            // (unscaled, BN-folded weights of 1e-2 .. 1e-3 leave it subnormal: 3e-6 .. 3e-5 relative instead of 2^-22); oscale undoes it, exactly
@@ -121,7 +125,7 @@ struct SeqLayer {
     // features of ConvParams the sequences never use (compile-time constants for the shared tile routine)
     static constexpr const int *pos = nullptr;
     static constexpr int pos_mul = 0, pos_add = 0, ups = 0, g_cin_off = 0, g_wgt_off = 0, g_cout_off = 0;
-    static constexpr int x3_out = 0, x3_res = 0, x3_in = 0;   // (split-operand tensors never run inside a sequence)
+    static constexpr int x3_out = 0, x3_res = 0, x3_in = 0, x3_ct = 0, x3_nreal = 0;   // (split-operand tensors never run inside a sequence)
     static constexpr const float *oscale = nullptr;
 };
 static_assert(sizeof(SeqLayer) == 104, "SeqLayer packing");
@@ -247,6 +251,7 @@ struct Tuning {
     int front_occ1 = 0;        // MEASURE builds: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
                                // step's tail run BESIDE the next frame's front end then?  No: +3.5 % per step (profiles/r06g_front_occupancy_ab.txt)
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
+    int x3_fused = 1;          // split-operand contexts: conv_wreg_kernel's fragment packs in fused order (a hi activation tile staged once for its two products)
     int wreg32 = 140;          // conv_wreg tile choice: 32 x 64 tiles where fewer than this many 64 x 64 tiles exist (0 = never): -8..15 % per under-filled
                                // launch, -2 % on the B = 1 step (profiles/r06w_wreg_32_row_tiles.txt)
     int pipe_join = 1;         // pipelined frame step: 1 = the join with the previous frame's tail is an in-stream gate kernel (two graphs per
