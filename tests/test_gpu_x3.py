@@ -107,6 +107,40 @@ def test_split_operand_context_end_to_end(B, inputs):
     assert errs["mask"] <= 5e-3 and errs["refine"] <= 5e-3, errs
 
 
+@pytest.mark.parametrize("variant", ["rpn", "base"])
+def test_split_operand_context_other_variants(variant):
+    """the two other model families of the reference (experiments/siamrpn_resnet/custom.py:87-93: two branches, no mask; experiments/siammask_base/
+    custom.py:100-112: three branches, the 63 x 63 mask head, no Refine) through the same split-operand trunk: cls / loc at the fp32 gate, the decoded
+    index = the oracle's, base's mask at the fp16 gate"""
+    from siammask_amd.custom import build
+    B = 2
+    z = synth.smooth_image_batch(B, 127, stream0=60)
+    x = synth.smooth_image_batch(B, 255, stream0=60)
+    o = Oracle(synth.state_dict(variant, "synthetic_damped"), variant)
+    o.template(z.astype(np.float64))
+    m = build(variant, dtype="f16x3", graph=True, max_batch=B)
+    m.load_state_dict(synth.torch_state_dict(variant, "synthetic_damped"))
+    m = m.eval().cuda()
+    m.template(torch.from_numpy(z).cuda())
+    twh = np.tile(np.array([[60.0, 80.0]], dtype=np.float64), (B, 1))
+    if variant == "rpn":
+        ocls, oloc = o.track(x.astype(np.float64))[:2]
+        out = m.track_step(torch.from_numpy(x).cuda(), torch.from_numpy(twh).cuda(), refine=False, mask_head=False)
+    else:
+        ocls, oloc, omask = o.track_mask(x.astype(np.float64))
+        out = m.track_step(torch.from_numpy(x).cuda(), torch.from_numpy(twh).cuda(), refine=False)
+    errs = {"cls": rel_err(out["cls"].cpu().numpy(), ocls), "loc": rel_err(out["loc"].cpu().numpy(), oloc)}
+    if variant == "base":
+        errs["mask"] = rel_err(out["mask"].cpu().numpy(), omask)
+    box = out["box"].cpu().numpy()
+    for b in range(B):
+        bid = decode_best(ocls[b], oloc[b], target_sz=(60.0, 80.0), scale_x=1.0)[0]
+        assert int(box[b, 7]) == bid, (variant, b, int(box[b, 7]), bid, errs)
+    print("f16x3 %s: %s" % (variant, {k: "%.1e" % v for k, v in errs.items()}))
+    assert errs["cls"] <= 1e-4 and errs["loc"] <= 1e-4, errs
+    assert errs.get("mask", 0.0) <= 5e-3, errs
+
+
 def test_split_operand_argmax_is_the_oracles_on_1024_streams():
     """the statistic of tests/test_gpu_argmax.py for the f16x3 context: device-decoded best_id vs the fp64 oracle's, all 1024 streams"""
     B, SEEDS = 64, 8
