@@ -31,12 +31,13 @@ def _inputs(B, n, seed):
 
 
 @pytest.mark.parametrize("depth", [1, 2])
-@pytest.mark.parametrize("B,dtype,frames", [(8, "f16", 7), (64, "f16", 4), (1, "f16", 5), (8, "f32", 3), (3, "f16", 4), (16, "f16", 4), (24, "f16", 3)])
+@pytest.mark.parametrize("B,dtype,frames", [(8, "f16", 7), (64, "f16", 4), (1, "f16", 5), (8, "f32", 3), (3, "f16", 4), (16, "f16", 4), (24, "f16", 3),
+                                            (8, "f16x3", 3), (1, "f16x3", 3)])
 def test_pipelined_rows_equal_serial_rows(B, dtype, frames, depth):
     """ring rows (box f64 + fp16 Refine logits) and the step's own outputs, frame by frame, serial vs pipelined -- B = 8 / 16 / 24 run
     layer2 .. adjust as the persistent sequence (which waits for the tail; depth 2 cuts the tail in two there, B = 24 without the
     mask head in the chain launch), B = 64 / 1 / 3 the per-launch kernels (main gate in front of the heads), fp32 ends its Refine in
-    the stand-alone ring commit launch"""
+    the stand-alone ring commit launch; the split-operand contexts (f16x3) run per-launch kernels with the fp16 chain tail"""
     m = _model(B, dtype)
     z, xs, twh = _inputs(B, frames, 500 + B)
     m.template(z)

@@ -68,15 +68,15 @@ def test_split_operand_convolution(cfg):
         assert ew <= 2e-5, (cfg, tile, ew)
 
 
-def _model(dtype, B):
+def _model(dtype, B, graph=True):
     from siammask_amd.custom import build
-    m = build("sharp", dtype=dtype, graph=True, max_batch=B)
+    m = build("sharp", dtype=dtype, graph=graph, max_batch=B)
     m.load_state_dict(synth.torch_state_dict("sharp", "synthetic_damped"))
     return m.eval().cuda()
 
 
-@pytest.mark.parametrize("B,inputs", [(2, "smooth"), (8, "random")])
-def test_split_operand_context_end_to_end(B, inputs):
+@pytest.mark.parametrize("B,inputs,graph", [(2, "smooth", True), (8, "random", True), (3, "smooth", False)])
+def test_split_operand_context_end_to_end(B, inputs, graph):
     gen = synth.smooth_image_batch if inputs == "smooth" else synth.image_batch
     z = gen(B, 127, stream0=40)
     x = gen(B, 255, stream0=40)
@@ -84,7 +84,7 @@ def test_split_operand_context_end_to_end(B, inputs):
     o.template(z.astype(np.float64))
     ocls, oloc, omask = o.track_mask(x.astype(np.float64))
     twh = np.tile(np.array([[60.0, 80.0]], dtype=np.float64), (B, 1))
-    m = _model("f16x3", B)
+    m = _model("f16x3", B, graph)          # (graph = False: eager launches, fresh output tensors per call)
     m.template(torch.from_numpy(z).cuda())
     out = m.track_step(torch.from_numpy(x).cuda(), torch.from_numpy(twh).cuda(), refine=True)
     errs = {"cls": rel_err(out["cls"].cpu().numpy(), ocls), "loc": rel_err(out["loc"].cpu().numpy(), oloc),
