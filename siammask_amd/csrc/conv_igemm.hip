@@ -656,6 +656,7 @@ template <typename T, int WM, int WN, int WK, int KT, int OUT_MODE, int NSTAGE>
 __global__ __launch_bounds__((SMK_NCW + 4) * 64, (WgPerCu<64 * (WM + WN) * KT, NSTAGE, SMK_EPI, SMK_NCW + 4>::waves_per_simd))
 void conv_igemm_kernel(const ConvBatch cb) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[IgemmLds<WM, WN, WK, KT, NSTAGE>::v];
+    set_wave_prio(cb.p[0].wave_prio);
     conv_igemm_body<T, WM, WN, WK, KT, OUT_MODE, NSTAGE>(cb, (int)blockIdx.x, (int)blockIdx.z, 0, smem);
 }
 
@@ -682,6 +683,7 @@ template <typename T, int WM, int WN, int WK, int AROWS, int NSLOT, int NPATCH>
 __global__ __launch_bounds__(512, (NPATCH == 2 ? 2 : 4)) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert(NPATCH == 1 || (NPATCH == 2 && NSLOT >= 3), "double-buffered patch needs a weight ring of >= 3");
     static_assert(WM * WN * WK == 4 && (WK == 1 || WK == 2), "four consumers, K split <= 2");
+    set_wave_prio(p.wave_prio);
     typedef Traits<T> TR;
     typedef typename TR::frag_t frag_t;
     constexpr int NCW = 4, NT = 512;

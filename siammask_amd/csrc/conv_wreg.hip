@@ -31,6 +31,7 @@ void conv_wreg_kernel(const ConvBatch cb) {
     for (int i = 1; i < CONV_BATCH_MAX; ++i)
         if (i < cb.n && (int)blockIdx.x >= cb.start[i]) pi = i;
     const ConvParams &p = cb.p[pi];
+    set_wave_prio(cb.p[0].wave_prio);
     const int wg_first = cb.start[pi], wg_count = cb.start[pi + 1] - cb.start[pi];
     constexpr int BM = 32 * FM, BN = 64 * WN;
     __shared__ __attribute__((aligned(16))) unsigned char smem[WregLds<FM, NSTAGE, WN * WK>::v];

@@ -340,6 +340,7 @@ struct smk_ctx {
     bool pipe_seq_exit = false, pipe_seq_exit_done = false;   // ... and the sequence launch raises the "chip is free" semaphore when it leaves
     bool tail2_pending = false;      // depth 2: the second part of the last frame's tail (chain + mask head) has not been launched yet
     GraphKey tail2_key, tail2_gated_key;   // ... its graph without / with the gate (flush form / the form the next step launches)
+    int wave_prio_now = 0;           // (recording a pipelined step's main part) the wave priority its launches carry: smk_tune main_prio
     bool pipe_gate_late = false;     // (recording a pipelined step) seq_track launches the main gate in front of the heads
     bool pipe_mark_fold = false, pipe_tail_fold = false, pipe_done_folded = false;   // (while a pipelined step's parts are being recorded)
     unsigned *pipe_sig = nullptr;    // signal memory: main parts completed (pipe_mark_kernel); the tail's hipStreamWaitValue32 target
@@ -837,6 +838,7 @@ static int conv_params(const smk_ctx *c, const PackedConv &pc, const Act &in, co
     // (measured, profiles/r02_tail_ab.txt: B=64 -1.3 % on the step, B=8 / B=1 within noise -> large launches only)
     if (o.nchw_out && g_tune.nchw_tn_major && p.xcd_mode == 1 && p.M >= 20000 && (double)p.M * p.N * 4 >= 4.0e6) p.xcd_mode = 2;
     p.prio = g_tune.prio;
+    p.wave_prio = c->wave_prio_now;
     {
         const double ib = (double)B * in.H * in.W * in.C * esize(c->dtype), wb = (double)pc.rows * pc.Kpad * esize(c->dtype);
         p.buf_lds = (g_tune.buf_lds && ib < 2.0e9 && wb < 2.0e9) ? 1 : 0;
@@ -1671,7 +1673,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
         // the front half ran as its own graph: p1 is where it left it
     } else if (c->dtype == DT_F16 && g_tune.stem_fused && stem_it->second.w_frag) {
         // one launch: frame -> p0 (kept for Refine) -> pooled x1, the p0 tile never leaves LDS in between (stem_pool.hip)
-        StemPoolParams sp_{x, stem_it->second.w_frag, stem_it->second.bias, p0.p, x1.p, B, S, s0, s1, stem_it->second.Kpad};
+        StemPoolParams sp_{x, stem_it->second.w_frag, stem_it->second.bias, p0.p, x1.p, B, S, s0, s1, stem_it->second.Kpad, c->wave_prio_now};
         ProfScope ps(c, s, "stem_pool", "stem_pool", 2.0 * B * s0 * s0 * 64.0 * 147.0,
                      (double)B * (3.0 * S * S * 4 + ((double)s0 * s0 + (double)s1 * s1) * 64 * 2));
         if (launch_stem_pool(sp_, s)) return fail(SMK_E_HIP, "stem_pool launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1751,7 +1753,7 @@ static int run_backbone(smk_ctx *c, const float *x, int B, int S, hipStream_t s,
                 lp.b1 = f1->second.bias; lp.b2 = f2->second.bias; lp.b3 = f3->second.bias;
                 lp.K1pad = f1->second.Kpad; lp.K2pad = f2->second.Kpad; lp.K3pad = f3->second.Kpad;
                 if (b == 0) { lp.wd = fd->second.w_frag16; lp.bd = fd->second.bias; lp.Kdpad = fd->second.Kpad; }
-                lp.B = B; lp.S = sp; lp.Cin = cur.C;
+                lp.B = B; lp.S = sp; lp.Cin = cur.C; lp.prio = c->wave_prio_now;
                 const double px = (double)B * sp * sp;
                 const double flop = 2.0 * px * (64.0 * cur.C + 64.0 * 576 + 256.0 * 64 + (b == 0 ? 256.0 * 64 : 0.0));
                 const double bytes = px * (cur.C + 256.0) * 2 + (64.0 * cur.C + 64 * 576 + 256 * 64 + (b == 0 ? 256 * 64 : 0)) * 2;
@@ -2685,6 +2687,7 @@ int smk_tune(const char *key, int value) {
     }
 #endif
     else if (!strcmp(key, "wreg96")) g_tune.wreg96 = value != 0;
+    else if (!strcmp(key, "main_prio")) { if (value < 0 || value > 3) return fail(SMK_E_ARG, "main_prio 0..3"); g_tune.main_prio = value; }
     else if (!strcmp(key, "x3_fused")) g_tune.x3_fused = value != 0;          // (read when a split-operand context packs its weights)
     else if (!strcmp(key, "pipe_prio")) {
 #ifndef SMK_MEASURE
@@ -2732,7 +2735,7 @@ int smk_tune_get(const char *key, int *value) {
         {"seq_first_stage", &g_tune.seq_first_stage}, {"seq_min_batch", &g_tune.seq_min_batch},
         {"seq_max_batch", &g_tune.seq_max_batch}, {"seq_extra_batch", &g_tune.seq_extra_batch}, {"seq_mult_max", &g_tune.seq_mult_max}, {"wreg_stages", &g_tune.wreg_stages}, {"chain", &g_tune.chain},
         {"halo_db", &g_tune.halo_db}, {"ksplit", &g_tune.ksplit}, {"halo", &g_tune.halo}, {"xc_ch", &g_tune.xc_ch}, {"xc_full", &g_tune.xc_full}, {"stem_fused", &g_tune.stem_fused}, {"l1_fused", &g_tune.l1_fused},
-        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"x3_fused", &g_tune.x3_fused}, {"pipe_prio", &g_tune.pipe_prio}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
+        {"buf_lds", &g_tune.buf_lds}, {"a_stage", &g_tune.a_stage}, {"npw", &g_tune.npw}, {"wreg_policy", &g_tune.wreg_policy}, {"mask_overlap", &g_tune.mask_overlap}, {"pipe_eager", &g_tune.pipe_eager}, {"pipe_join", &g_tune.pipe_join}, {"wreg96", &g_tune.wreg96}, {"main_prio", &g_tune.main_prio}, {"x3_fused", &g_tune.x3_fused}, {"pipe_prio", &g_tune.pipe_prio}, {"wreg32", &g_tune.wreg32}, {"pp", &g_tune.pp}, {"front_occ1", &g_tune.front_occ1}, {"seq_yres", &g_tune.seq_yres}, {"seq_search", &g_tune.seq_search}, {"pipe_late", &g_tune.pipe_late}, {"pipe_two_form", &g_tune.pipe_two_form}, {"pipe_sig", &g_tune.pipe_sig},
         {"nt_store", &g_tune.nt_store}, {"prio", &g_tune.prio}, {"kt", &g_tune.kt}};
     for (const auto &k : knobs)
         if (!strcmp(key, k.name)) { *value = *k.slot; return 0; }
@@ -2961,6 +2964,7 @@ static int step_pipelined_enqueue(smk_ctx *c, const float *x, int B, int flags, 
     auto front = [&](hipStream_t st) { return run_backbone(c, x, B, 255, st, PH_FRONT); };
     auto mid = [&](hipStream_t st) { return step_track_decode(c, x, B, flags, target_wh, cls, loc, mask, box_out, refine_out, st, false, PH_BACK); };
     auto main_ = [&](hipStream_t st) {
+        struct PrioScope { smk_ctx *c; PrioScope(smk_ctx *c_) : c(c_) { c->wave_prio_now = g_tune.main_prio; } ~PrioScope() { c->wave_prio_now = 0; } } prio_scope(c);
         CHK(front(st));
         if (!late) {
             if (launch_pipe_gate(c->pipe_cnt, c->seq_err, c->seq_err_hdev, st, 0, nullptr, c->pipe_cnt + 8)) return fail(SMK_E_HIP, "pipe_gate launch failed");

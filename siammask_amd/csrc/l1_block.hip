@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, 2) void l1_block_kernel(const L1BlockParams p)
     unsigned char *xs = smem, *t1 = smem + L::XS, *t2 = t1 + L::T1, *ys = t2 + L::T2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    set_wave_prio(p.prio);                                    // (smk_tune main_prio, see stem_pool.hip)
     const int fr = lane & 15, kq = lane >> 4;
     const int tpr = (p.S + LB_T - 1) / LB_T;
     const int b = blockIdx.x / (tpr * tpr);

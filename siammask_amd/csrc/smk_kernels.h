@@ -63,6 +63,7 @@ struct ConvParams {
     int ci_shift;          // log2(Ci) when Ci is a power of two, else -1 (division fallback)
     int kw_magic;          // tap / kw == (tap * kw_magic) >> 16  for tap < 4096
     int prio;              // s_setprio of the consumer waves (0..3); -1: producers at 1
+    int wave_prio;         // s_setprio of EVERY wave of the launch (0..3; smk_tune main_prio): a pipelined step's main part above the previous frame's tail it shares SIMDs with
     int buf_lds;           // producers use buffer_load ... lds (SRD + 32-bit offsets, hardware zero fill)
     int a_stage;           // conv_wreg / conv_seq producers: 1 = activation rows global -> VGPR -> ds_write (A/B knob "a_stage")
     int res_nt;            // conv_wreg / conv_seq: residual rows fetched non-temporally (A/B knob "res_nt")
@@ -248,6 +249,8 @@ struct Tuning {
     int a_stage = 0;           // conv_wreg / conv_seq: activation rows through registers instead of LDS-DMA (see ConvParams::a_stage)
     int pp = 1;                // fp16 NHWC convolutions with M >= 32768 rows, K >= 2304 and >= 200 tiles of 256 x 256 through conv_pp_kernel (0 off, 1 the
                                // rule in engine.cpp pp_choice, 2 wherever eligible)
+    int main_prio = 3;         // pipelined steps: wave priority (s_setprio 0..3) of the MAIN part's launches (stem_pool, l1_block, the per-layer convolutions) -- they share
+                               // SIMDs with the previous frame's tail, whose launches stay at 0: B = 1 +1.2 %, f16x3 +1.4 .. 2.4 %, B = 8 / 64 unchanged (profiles/r06bb_main_part_wave_priority.txt)
     int front_occ1 = 0;        // MEASURE builds: bit 0 l1_block_kernel, bit 1 stem_pool_kernel limited to ONE workgroup per CU (padding LDS): does the pipelined
                                // step's tail run BESIDE the next frame's front end then?  No: +3.5 % per step (profiles/r06g_front_occupancy_ab.txt)
     int wreg96 = 1;            // conv_wreg tile choice: 96 x 256 tiles where 128 x 256 would leave a partial round (see wreg_choice)
@@ -347,11 +350,18 @@ struct CorrHeadParams {
 };
 int launch_corr_head(const CorrHeadParams &p, void *stream);
 
+#ifdef __HIPCC__
+__device__ __forceinline__ void set_wave_prio(int prio) {        // (s_setprio takes an immediate)
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+}
+#endif
 // DT_F16X3: a split tensor is stored as X3_PLANES channel planes [hi | lo] (the operand of a tripled-K pack is [hi | hi | lo]: ConvParams::x3_in)
 constexpr int X3_PLANES = 2;
 struct PoolParams { const void *in; void *out; int B, H, W, C, Ho, Wo; int x3; };     // x3: C channels stored as [hi | lo] planes (2 C per pixel)
 // the fused stem (stem_pool.hip): NCHW f32 frame -> conv1 7x7/2 + BN + ReLU -> p0 [B][s0][s0][64] -> maxpool 3x3/2 p1 -> x1 [B][s1][s1][64], f16
-struct StemPoolParams { const float *in; const void *wgt_frag; const float *bias; void *p0; void *x1; int B, S, s0, s1, Kpad; };
+struct StemPoolParams { const float *in; const void *wgt_frag; const float *bias; void *p0; void *x1; int B, S, s0, s1, Kpad; int prio; };   // prio: wave priority (s_setprio)
 
 struct CvtInParams { const float *in; void *out; int B, C, H, W, Cpad; int pairs; int x3; };  // NCHW f32 -> NHWC dtype (x3: [hi | lo] planes of Cpad channels)
 // pairs = 1 (stem input, C <= 4): [B][H][ceil(W/2)][2 pixels x 4 channels], missing pixel / channel = 0
@@ -484,6 +494,7 @@ struct L1BlockParams {
     const float *b1, *b2, *b3, *bd;
     int B, S, Cin, K1pad, K2pad, K3pad, Kdpad;
     unsigned long long *clk;           // optional [6]: phase stamps of workgroup 0 (SMK_L1_CLK=1)
+    int prio;                          // wave priority (s_setprio)
 };
 int launch_l1_block(const L1BlockParams &p, void *stream);
 int launch_cvt_in(const CvtInParams &p, int dtype, void *stream);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const StemPoolParams 
     _Float16 *p0t = (_Float16 *)(smem + SP_PATCH_BYTES);      // [320][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    set_wave_prio(p.prio);                                    // (smk_tune main_prio: the waves of this kernel issue ahead of a co-resident kernel's)
     const int tpr = (p.s1 + SP_TP - 1) / SP_TP;               // tiles per row
     const int b = blockIdx.x / (tpr * tpr);
     const int tt = blockIdx.x - b * (tpr * tpr);
