@@ -1,4 +1,5 @@
 #!/bin/bash
+# (RECORD ONLY: the smk_tune tail_split knob and its code were removed again after this measurement -- profiles/r06cc_mask_head_outside_the_chain_launch.txt)
 # Round 6: pipelined step with the mask head as its own launch on a second side stream (own gate + completion semaphore; 64 KB of LDS per workgroup) instead of inside chain_mask_kernel (140 KB for each of its ~650
 # workgroups: none of them shares a CU with the next frame's front end): parity of the pipeline suite under the knob, then A/B
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/r06cc; rm -rf $O; mkdir -p $O
